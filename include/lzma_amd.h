@@ -1,0 +1,143 @@
+/*
+ * lzma_amd -- MI355X (gfx950) LZMA engine, C ABI.
+ *
+ * This is the drop-in boundary for the hot path of the Go package itchio/lzma
+ * (paths below are relative to that package's root).  Each entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; blocking;
+ * callable from any thread; nothing is retained after a call returns (cgo
+ * pointer rule).
+ *
+ * Two families of entry points:
+ *   - host-buffer calls (lzma_amd_*): take host memory, stage through HBM.
+ *   - device calls (lzma_amd_*_dev): inputs/outputs already resident in HBM on
+ *     the current HIP device; `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream).  They enqueue work and synchronize the stream
+ *     before returning unless stated otherwise.
+ */
+#ifndef LZMA_AMD_H
+#define LZMA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-call / per-stream status.  Decoder values map onto the reference's error
+ * values: HEADER = headerError, STREAM = streamError (lzma_decoder.go:91-95),
+ * TRUNCATED = the io.EOF the reference surfaces when the payload ends early
+ * (range_coder.go:82-85), ARG = *argumentValueError (lzma_encoder.go:26-34). */
+enum {
+    LZMA_AMD_OK = 0,
+    LZMA_AMD_ERR_HEADER = 1,
+    LZMA_AMD_ERR_STREAM = 2,
+    LZMA_AMD_ERR_TRUNCATED = 3,
+    LZMA_AMD_ERR_OUT_CAP = 4,
+    LZMA_AMD_ERR_ARG = 5,
+    LZMA_AMD_ERR_NOMEM = 6,
+    LZMA_AMD_ERR_HIP = 7,
+    LZMA_AMD_ERR_UNSUPPORTED = 8
+};
+
+/* Encoder parameters: the fields of the reference's compressionLevel
+ * (lzma_encoder.go:85-94) made explicit, because two of the benchmark
+ * configurations are not rows of its `levels` table (lzma_encoder.go:97-108).
+ * Ranges are those of checkValues (lzma_encoder.go:110-129). */
+typedef struct {
+    uint32_t dict_log; /* 12..29; dictionary = 1 << dict_log                 */
+    uint32_t fb;       /* 5..273; fast bytes = matchMaxLen of the BT4 finder */
+    uint32_t lc, lp, pb;
+    uint32_t cut_value; /* reserved: the GPU finder is always exhaustive
+                           (equivalent to lzBinTree.cutValue = infinity,
+                           lz_bin_tree.go:26,41,200); must be 0              */
+    int32_t eos;        /* 1: size field -1 and end marker (size == -1 in
+                           NewWriterSizeLevel, lzma_encoder.go:1012-1015)    */
+} lzma_amd_params;
+
+/* levels[level] of lzma_encoder.go:97-108; returns LZMA_AMD_ERR_ARG outside
+ * 1..9 as encoder() does (lzma_encoder.go:997-999). */
+int lzma_amd_params_from_level(int level, int eos, lzma_amd_params *p);
+
+/* Number of usable HIP devices (0 if none). */
+int lzma_amd_device_count(void);
+/* Select the device used by the calling thread's subsequent calls. */
+int lzma_amd_set_device(int device);
+/* Message for the calling thread's most recent failing call ("" if none). */
+const char *lzma_amd_last_error(void);
+const char *lzma_amd_version(void);
+
+/* Worst-case encoded size of one chunk of n bytes, header included. */
+size_t lzma_amd_encode_bound(size_t n);
+
+/* ---------------------------------------------------------------- match finder
+ * Replaces lzBinTree.getMatches called at every position of one stream
+ * (lz_bin_tree.go:115-253; skip, :255-337, performs the same insertions), for
+ * numHashBytes = 4, with the tree search exhaustive.  For each position i of
+ * data[0..n): counts[i] = number of pairs, and the pairs of position i are
+ * pairs[2*k], pairs[2*k+1] = (length, distance-1) for k in
+ * [offsets[i], offsets[i]+counts[i]), lengths strictly increasing -- the same
+ * values and order the reference writes into `distances`.
+ * offsets may be NULL.  pairs_cap is in pairs; *total_pairs is always set, and
+ * LZMA_AMD_ERR_OUT_CAP is returned if it exceeds pairs_cap (counts still valid).
+ */
+int lzma_amd_bt4_matches(const uint8_t *data, size_t n, uint32_t dict_size, uint32_t fb,
+                         uint32_t *counts, uint64_t *offsets, uint32_t *pairs,
+                         size_t pairs_cap, size_t *total_pairs);
+
+/* Same, all pointers in HBM.  d_total_pairs is a device uint64. */
+int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_t dict_size, uint32_t fb,
+                             uint32_t *d_counts, uint64_t *d_offsets, uint32_t *d_pairs,
+                             size_t pairs_cap, uint64_t *d_total_pairs, void *stream);
+
+/* --------------------------------------------------------------------- encoder
+ * Replaces encoder.encoder() run once per chunk (lzma_encoder.go:989-1107:
+ * header, getOptimum/backward optimal parse :331-797, codeOneBlock :859-978,
+ * range coder range_coder.go:131-220): chunk c is in[in_off[c]..in_off[c+1])
+ * and becomes one complete .lzma stream (13-byte header + payload) written at
+ * out + out_off[c], of out_sizes[c] bytes; out_off[c+1]-out_off[c] is the
+ * capacity given to chunk c (use lzma_amd_encode_bound).  status[c] is per
+ * chunk.  Every chunk is an independent stream, as if passed to its own
+ * NewWriterSizeLevel.  The header's size field is the chunk length unless
+ * p->eos.
+ */
+int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off, size_t n_chunks,
+                           const lzma_amd_params *p, uint8_t *out, const uint64_t *out_off,
+                           uint64_t *out_sizes, int32_t *status);
+
+int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks,
+                               size_t in_total, const lzma_amd_params *p, uint8_t *d_out,
+                               const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                               int32_t *d_status, void *stream);
+
+/* --------------------------------------------------------------------- decoder
+ * Replaces decoder.decoder() run once per stream (lzma_decoder.go:306-349;
+ * doDecode :218-304; range decoder range_coder.go:27-105; output window
+ * lz_window.go:9-80): stream s is in[in_off[s]..in_off[s+1]), a complete .lzma
+ * stream including its 13-byte header; its output goes to out + out_off[s]
+ * with capacity out_off[s+1]-out_off[s]; out_sizes[s] receives the number of
+ * bytes produced and status[s] the per-stream status.  On a non-OK status the
+ * bytes produced before the error are left in place (the reference would have
+ * delivered only whole flushed windows of them).
+ */
+int lzma_amd_decode_batch(const uint8_t *in, const uint64_t *in_off, size_t n_streams,
+                          uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                          int32_t *status);
+
+int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_streams,
+                              uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                              int32_t *d_status, void *stream);
+
+/* Header fields of one stream (props.decodeProps, lzma_decoder.go:175-190, and
+ * the size field :318-322), host-side helper for sizing decode outputs. */
+int lzma_amd_parse_header(const uint8_t *in, size_t n, uint32_t *lc, uint32_t *lp, uint32_t *pb,
+                          uint32_t *dict_size, int64_t *unpack_size);
+
+/* Milliseconds of device time (hipEvent) spent in the kernels of the calling
+ * thread's most recent *_dev call, by phase; any pointer may be NULL. */
+void lzma_amd_last_timing(float *ms_total, float *ms_finder, float *ms_coder);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,156 @@
+// Batched LZMA decoder for gfx950: many independent .lzma streams decoded
+// concurrently, one 64-lane wavefront (= one workgroup) per stream.
+//
+// Replaces decoder.decoder()/doDecode of the reference (lzma_decoder.go:218-349)
+// applied once per stream.  The probability models of a stream (15.6 KiB at
+// lc+lp <= 3) live in LDS, so ten streams are resident per CU; the range-decoder
+// state is wave-uniform and is kept in scalar registers; the match copy is done
+// by all 64 lanes.  Streams whose literal coder does not fit in LDS (lc+lp > 3)
+// are deferred to a second, persistent launch that keeps the literal models in a
+// per-workgroup HBM scratch area.
+//
+// Roofline class: HBM-bound in principle (reads C compressed bytes, writes N raw
+// bytes per stream), serial-dependency-bound in practice.
+#include "host_util.hpp"
+#include "lzma_dec_core.hpp"
+
+namespace {
+
+constexpr uint32_t kLitLdsLog = 3;                      // lc+lp handled from LDS
+constexpr uint32_t kLitLds = 0x300u << kLitLdsLog;      // 6144 models
+constexpr uint32_t kLdsProbs = lz::kNumBaseProbs + kLitLds;
+constexpr int32_t kPending = -1;
+
+// One workgroup (one wave) per stream.  BIG == false: grid = n_streams, streams
+// with lc+lp > kLitLdsLog are appended to big_list.  BIG == true: persistent grid
+// over big_list, literal models in lit_scratch[blockIdx].
+template <bool BIG>
+__global__ __launch_bounds__(64) void decode_kernel(
+    const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint64_t n_streams,
+    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+    uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint32_t *big_count,
+    uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride) {
+    __shared__ lz::prob_t s_probs[BIG ? lz::kNumBaseProbs : kLdsProbs];
+    const uint32_t lane = threadIdx.x;
+
+    uint64_t first = blockIdx.x, step = gridDim.x;
+    uint64_t count = BIG ? (uint64_t)*big_count : n_streams;
+    for (uint64_t it = first; it < count; it += step) {
+        const uint64_t s = BIG ? (uint64_t)big_list[it] : it;
+        const uint64_t ib = in_off[s], ie = in_off[s + 1];
+        const uint64_t ob = out_off[s], oe = out_off[s + 1];
+        const uint8_t *sin = in + ib;
+        const uint64_t n = ie - ib;
+        lz::Header h;
+        int32_t hs = lz::parse_header(sin, n, h);
+        if (hs != lz::ST_OK) {
+            if (lane == 0) {
+                status[s] = hs;
+                out_sizes[s] = 0;
+            }
+            continue;
+        }
+        const uint32_t lit_n = 0x300u << (h.lc + h.lp);
+        if (!BIG && h.lc + h.lp > kLitLdsLog) {
+            if (lane == 0) {
+                uint32_t k = atomicAdd(big_count, 1u);
+                big_list[k] = (uint32_t)s;
+                status[s] = kPending;
+            }
+            continue;
+        }
+        __syncthreads();  // previous stream's models are no longer in use
+        for (uint32_t i = lane; i < lz::kNumBaseProbs; i += 64) s_probs[i] = lz::kProbInit;
+        lz::DecodeResult r;
+        if (BIG) {
+            lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_scratch_stride;
+            for (uint32_t i = lane; i < lit_n; i += 64) lit[i] = lz::kProbInit;
+            __syncthreads();
+            r = lz::decode_stream(sin, n, h, s_probs, lit, out + ob, oe - ob, lane, 64u);
+        } else {
+            for (uint32_t i = lane; i < lit_n; i += 64) s_probs[lz::P_LIT + i] = lz::kProbInit;
+            __syncthreads();
+            r = lz::decode_stream(sin, n, h, s_probs, s_probs + lz::P_LIT, out + ob, oe - ob, lane,
+                                  64u);
+        }
+        if (lane == 0) {
+            status[s] = r.status;
+            out_sizes[s] = r.out_size;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off,
+                                         size_t n_streams, uint8_t *d_out,
+                                         const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                                         int32_t *d_status, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    lzh::tls().ms_total = lzh::tls().ms_finder = lzh::tls().ms_coder = 0.f;
+    if (n_streams == 0) return LZMA_AMD_OK;
+    if (!d_in || !d_in_off || !d_out || !d_out_off || !d_out_sizes || !d_status)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
+    if (n_streams > 0x7FFFFFFFull)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: too many streams in one call");
+    lzh::DevBuf big;  // [0] = count, [1..] = list of deferred stream indices
+    LZ_HIP(big.alloc((n_streams + 1) * sizeof(uint32_t)));
+    LZ_HIP(hipMemsetAsync(big.p, 0, sizeof(uint32_t), st));
+    lzh::Timer tm;
+    tm.start(st);
+    hipLaunchKernelGGL(decode_kernel<false>, dim3((unsigned)n_streams), dim3(64), 0, st, d_in,
+                       d_in_off, (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
+                       big.as<uint32_t>(), big.as<uint32_t>() + 1, (lz::prob_t *)nullptr,
+                       (uint64_t)0);
+    LZ_HIP(hipGetLastError());
+    uint32_t n_big = 0;
+    LZ_HIP(hipMemcpyAsync(&n_big, big.p, sizeof n_big, hipMemcpyDeviceToHost, st));
+    LZ_HIP(hipStreamSynchronize(st));
+    lzh::DevBuf scratch;
+    if (n_big > 0) {
+        const unsigned wgs = n_big < 64 ? n_big : 64;
+        const uint64_t stride = 0x300ull << 12;  // lc+lp <= 12 (lc <= 8, lp <= 4)
+        LZ_HIP(scratch.alloc((size_t)wgs * stride * sizeof(lz::prob_t)));
+        hipLaunchKernelGGL(decode_kernel<true>, dim3(wgs), dim3(64), 0, st, d_in, d_in_off,
+                           (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
+                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(),
+                           stride);
+        LZ_HIP(hipGetLastError());
+    }
+    tm.stop();
+    LZ_HIP(hipStreamSynchronize(st));
+    lzh::tls().ms_total = lzh::tls().ms_coder = tm.ms();
+    return LZMA_AMD_OK;
+}
+
+extern "C" int lzma_amd_decode_batch(const uint8_t *in, const uint64_t *in_off, size_t n_streams,
+                                     uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,
+                                     int32_t *status) {
+    if (n_streams == 0) return LZMA_AMD_OK;
+    if (!in_off || !out_off || !out_sizes || !status)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
+    const uint64_t in_base = in_off[0], in_total = in_off[n_streams] - in_base;
+    const uint64_t out_base = out_off[0], out_total = out_off[n_streams] - out_base;
+    for (size_t s = 0; s < n_streams; s++)
+        if (in_off[s + 1] < in_off[s] || out_off[s + 1] < out_off[s])
+            return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: offsets must be non-decreasing");
+    lzh::DevBuf d_in, d_io, d_out, d_oo, d_sz, d_st;
+    LZ_HIP(d_in.alloc(in_total));
+    LZ_HIP(d_io.alloc((n_streams + 1) * 8));
+    LZ_HIP(d_out.alloc(out_total));
+    LZ_HIP(d_oo.alloc((n_streams + 1) * 8));
+    LZ_HIP(d_sz.alloc(n_streams * 8));
+    LZ_HIP(d_st.alloc(n_streams * 4));
+    if (in_total) LZ_HIP(hipMemcpy(d_in.p, in + in_base, in_total, hipMemcpyHostToDevice));
+    LZ_HIP(hipMemcpy(d_io.p, in_off, (n_streams + 1) * 8, hipMemcpyHostToDevice));
+    LZ_HIP(hipMemcpy(d_oo.p, out_off, (n_streams + 1) * 8, hipMemcpyHostToDevice));
+    // device copies index from the batch's own base
+    int rc = lzma_amd_decode_batch_dev(d_in.as<uint8_t>() - in_base, d_io.as<uint64_t>(), n_streams,
+                                       d_out.as<uint8_t>() - out_base, d_oo.as<uint64_t>(),
+                                       d_sz.as<uint64_t>(), d_st.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    if (out_total) LZ_HIP(hipMemcpy(out + out_base, d_out.p, out_total, hipMemcpyDeviceToHost));
+    LZ_HIP(hipMemcpy(out_sizes, d_sz.p, n_streams * 8, hipMemcpyDeviceToHost));
+    LZ_HIP(hipMemcpy(status, d_st.p, n_streams * 4, hipMemcpyDeviceToHost));
+    return LZMA_AMD_OK;
+}
