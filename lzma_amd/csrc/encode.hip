@@ -21,11 +21,18 @@ namespace {
 constexpr uint32_t kLitLdsLog = 3;
 constexpr uint32_t kMdistWords = 2 * (lz::kMatchMax + 1) + 2;
 
+// Match list of a chunk position, read from the finder's results.
 struct MfFunctor {
-    lz::MfTables t;
-    uint32_t job_start, job_end, lane;
+    const uint64_t *meta;
+    const uint32_t *arena;
+    uint32_t job_start, lane;
     __device__ uint32_t operator()(uint32_t pos, uint32_t *out) const {
-        return lz::mf_find(t, job_start + pos, job_start, job_end, out, lane);
+        const uint64_t m = meta[job_start + pos];
+        const uint32_t c = lz::mf_meta_count(m);
+        const uint32_t *src = arena + 2 * lz::mf_meta_off(m);
+        for (uint32_t k = lane; k < 2 * c; k += 64) out[k] = src[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        return c;
     }
 };
 
@@ -47,7 +54,10 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t lc, uint32_t lp, uint32
 // Chunks [c0, c0 + nchunks) of the call; their bytes start at data offset
 // in_off[c] - base inside t.data.
 template <bool LIT_LDS>
-__global__ __launch_bounds__(64) void encode_kernel(lz::MfTables t, const uint64_t *__restrict__ in_off,
+__global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ data,
+                                                    const uint64_t *__restrict__ mf_meta,
+                                                    const uint32_t *__restrict__ mf_arena,
+                                                    const uint64_t *__restrict__ in_off,
                                                     uint64_t base, uint64_t c0, uint32_t nchunks,
                                                     lz::EncParams ep, uint8_t *__restrict__ out,
                                                     const uint64_t *__restrict__ out_off,
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(64) void encode_kernel(lz::MfTables t, const uint64
         __syncthreads();
 
         lz::Encoder<MfFunctor, lz::prob_t, lz::prob_t, uint16_t> e;
-        e.data = t.data + jb;
+        e.data = data + jb;
         e.n = je - jb;
         e.probs = probs;
         e.lit = lit;
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(64) void encode_kernel(lz::MfTables t, const uint64
         e.mdist = mdist;
         e.out = out + ob + lz::kHeaderSize;
         e.out_cap = oe - ob - lz::kHeaderSize;
-        e.mf = MfFunctor{t, jb, je, lane};
+        e.mf = MfFunctor{mf_meta, mf_arena, jb, lane};
         e.ep = ep;
         e.run(small);
         if (lane == 0) {
@@ -166,6 +176,9 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         lzh::MfWorkspace ws;
         rc = ws.build(d_in + base, nbytes, ep.dict_size, ep.fb, st);
         if (rc) return rc;
+        uint64_t total_pairs = 0;
+        rc = ws.scan(d_in_off, base, c0, nchunks, st, &total_pairs);
+        if (rc) return rc;
         t_mf.stop();
         unsigned grid = nchunks;
         const unsigned max_grid = lit_lds ? 256u * 16u : 512u;
@@ -176,11 +189,13 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         if (!lit_lds) LZ_HIP(lit.alloc((size_t)grid * lit_stride * sizeof(lz::prob_t)));
         t_enc.start(st);
         if (lit_lds)
-            hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(64), L.total, st, ws.view, d_in_off,
+            hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(64), L.total, st, d_in + base, ws.d_meta(),
+                               ws.d_arena(), d_in_off,
                                base, (uint64_t)c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
                                opt.as<lz::Opt>(), (lz::prob_t *)nullptr, (uint64_t)0);
         else
-            hipLaunchKernelGGL(encode_kernel<false>, dim3(grid), dim3(64), L.total, st, ws.view, d_in_off,
+            hipLaunchKernelGGL(encode_kernel<false>, dim3(grid), dim3(64), L.total, st, d_in + base, ws.d_meta(),
+                               ws.d_arena(), d_in_off,
                                base, (uint64_t)c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
                                opt.as<lz::Opt>(), lit.as<lz::prob_t>(), lit_stride);
         t_enc.stop();

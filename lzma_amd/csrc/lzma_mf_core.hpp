@@ -12,7 +12,7 @@
 // nodes are the *record breakers* when the bucket's in-window positions are scanned
 // from newest to oldest, stopping at the first that reaches lenLimit -- a pure
 // function of the window.  That scan is what this file implements, 64 candidates
-// at a time, one per lane.
+// at a time, one per lane, record breakers picked with a ballot.
 //
 // To avoid scanning whole buckets (about 1400 candidates per position on text),
 // positions are also grouped by their exact first 8 bytes.  All candidates sharing
@@ -20,10 +20,11 @@
 // the newest of them (Q*) shares fewer than 8.  So the bucket is scanned only down
 // to Q*, and from Q* on the (much shorter) 8-gram group is scanned instead.
 //
-// Inputs are arrays produced by stable radix sorts of (key, position):
-//   ord4/skey4: positions and hash-4 slots in (slot, position) order; rank4[P]
-//   ord8: positions in (first 8 bytes, position) order; rank8[P]
-//   prev2/prev3: previous position with the same hash-2 / hash-3 slot
+// Both scans stream: the sorted tables carry, next to each position, the bytes
+// needed to compare it (first 8 bytes in the bucket table, bytes 8..15 in the
+// 8-gram table), so the lanes read consecutive 16-byte entries instead of
+// gathering from the window; only common prefixes of 16 bytes or more touch the
+// window itself.
 #pragma once
 #include "lzma_common.hpp"
 
@@ -31,12 +32,31 @@ namespace lz {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// One entry of a sorted table: a position, the index of the first entry of its
+// bucket/group, and 8 bytes of its text (see above).
+struct __attribute__((aligned(16))) MfEnt {
+    uint32_t pos, gstart;
+    uint64_t sig;
+};
+// Per position: its index in both tables and the previous position with the same
+// hash-2 / hash-3 slot (kNone if there is none).
+struct __attribute__((aligned(16))) MfInfo {
+    uint32_t rank4, rank8, prev2, prev3;
+};
+
 struct MfTables {
     const uint8_t *data;  // all jobs' bytes, positions are offsets into it
     uint32_t n;           // bytes in data
-    const uint32_t *ord4, *skey4, *rank4, *ord8, *rank8, *prev2, *prev3;
+    const MfEnt *ent4;    // (hash-4 slot, position) order, sig = bytes 0..7
+    const MfEnt *ent8;    // (bytes 0..7, position) order, sig = bytes 8..15
+    const MfInfo *info;
     uint32_t dict, fb, use8;
 };
+
+// Result word per position: pair offset in the arena (upper 48 bits) and count.
+LZ_HD uint64_t mf_meta(uint64_t off, uint32_t count) { return (off << 16) | count; }
+LZ_HD uint64_t mf_meta_off(uint64_t m) { return m >> 16; }
+LZ_HD uint32_t mf_meta_count(uint64_t m) { return (uint32_t)(m & 0xFFFF); }
 
 #if defined(__HIPCC__)
 
@@ -48,13 +68,14 @@ LZ_D uint64_t mf_load8(const uint8_t *data, uint32_t n, uint32_t i) {
         return v;
     }
     uint64_t v = 0;
-    for (uint32_t k = 0; k < 8 && i + k < n; k++) v |= (uint64_t)data[i + k] << (8 * k);
+    for (uint32_t k = 0; k < 8 && i < n && i + k < n; k++) v |= (uint64_t)data[i + k] << (8 * k);
     return v;
 }
 
-// Common prefix length of the strings at P and Q (Q < P), at most `limit`.
-LZ_D uint32_t mf_lcp(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q, uint32_t limit) {
-    uint32_t l = 0;
+// Common prefix of the strings at P and Q (Q < P) beyond `from` known-equal bytes.
+LZ_D uint32_t mf_extend(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q, uint32_t from,
+                        uint32_t limit) {
+    uint32_t l = from;
     while (l < limit) {
         uint64_t x = mf_load8(data, n, P + l) ^ mf_load8(data, n, Q + l);
         if (x != 0) {
@@ -67,11 +88,12 @@ LZ_D uint32_t mf_lcp(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q, ui
 }
 
 // Match list of position P of the job [job_start, job_end).  Called by all 64 lanes
-// of a wave with identical arguments; `out` (LDS or global, 2*(kMatchMax+1) words)
-// receives (length, distance-1) pairs; returns the number of pairs.
-template <class OutT>
+// of a wave with identical arguments; emit(k, length, distance-1) is called once per
+// pair, k = 0, 1, ... (identically on every lane); returns the number of pairs.
+// A later emit with a smaller k overwrites (the reference drops seed pairs that way).
+template <class Emit>
 LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_t job_end,
-                      OutT *out, uint32_t lane) {
+                      Emit emit, uint32_t lane) {
     const uint32_t left = job_end - P;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
     if (len_limit < 4) return 0;  // lz_bin_tree.go:121-124
@@ -80,28 +102,29 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
     uint32_t W = P > t.dict ? P - t.dict : 0;
     if (W < job_start) W = job_start;
 
-    const uint32_t r4 = t.rank4[P];
-    const uint32_t key = t.skey4[r4];
+    const MfInfo inf = t.info[P];
+    const uint32_t r4 = inf.rank4;
+    const MfEnt me4 = t.ent4[r4];
+    const uint32_t g4 = me4.gstart;
+    const uint64_t p8 = me4.sig;  // P's first 8 bytes
     uint32_t q4 = kNone;
-    if (r4 > 0 && t.skey4[r4 - 1] == key) {
-        q4 = t.ord4[r4 - 1];
+    if (r4 > g4) {
+        q4 = t.ent4[r4 - 1].pos;
         if (q4 < job_start) q4 = kNone;
     }
-    const uint32_t q2 = t.prev2[P], q3 = t.prev3[P];
-    const uint32_t b0 = data[P];
+    const uint32_t q2 = inf.prev2, q3 = inf.prev3;
+    const uint32_t b0 = (uint32_t)p8 & 0xFF;
     uint32_t n = 0, max_len = 1, last = q2;
     // seeds, lz_bin_tree.go:154-180
     if (q2 != kNone && q2 >= W && data[q2] == b0) {
         max_len = 2;
-        out[0] = 2;
-        out[1] = P - q2 - 1;
+        emit(0u, 2u, P - q2 - 1);
         n = 1;
     }
     if (q3 != kNone && q3 >= W && data[q3] == b0) {
         if (q3 == q2) n--;
         max_len = 3;
-        out[2 * n] = 3;
-        out[2 * n + 1] = P - q3 - 1;
+        emit(n, 3u, P - q3 - 1);
         n++;
         last = q3;
     }
@@ -111,53 +134,60 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
     }
 
     // newest position sharing P's first 8 bytes
-    uint32_t qstar = kNone, r8 = 0;
+    uint32_t qstar = kNone, r8 = 0, g8 = 0;
+    uint64_t pn8 = 0;
     if (t.use8 && len_limit >= 8) {
-        r8 = t.rank8[P];
-        if (r8 > 0) {
-            uint32_t q = t.ord8[r8 - 1];
-            if (q >= W && mf_load8(data, t.n, q) == mf_load8(data, t.n, P)) qstar = q;
+        r8 = inf.rank8;
+        const MfEnt me8 = t.ent8[r8];
+        g8 = me8.gstart;
+        pn8 = me8.sig;  // P's bytes 8..15
+        if (r8 > g8) {
+            uint32_t q = t.ent8[r8 - 1].pos;
+            if (q >= W) qstar = q;
         }
     }
     const uint32_t low_a = qstar != kNone ? qstar + 1 : W;
 
     // ---- scan of the hash-4 bucket, newest first, down to low_a
-    for (uint32_t base = r4;; base -= 64) {
-        bool valid = base > lane;  // candidate index base-1-lane >= 0
-        uint32_t Q = 0;
+    for (uint32_t base = r4; base > g4; base -= 64) {
+        bool valid = base > g4 + lane;  // index base-1-lane is still inside the bucket
+        uint32_t Q = 0, l = 0;
         if (valid) {
-            const uint32_t j = base - 1 - lane;
-            Q = t.ord4[j];
-            valid = t.skey4[j] == key && Q >= low_a;
+            const MfEnt e = t.ent4[base - 1 - lane];
+            Q = e.pos;
+            valid = Q >= low_a;
+            const uint64_t x = e.sig ^ p8;
+            l = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
+            if (l >= 8 && len_limit > 8) l = mf_extend(data, t.n, P, Q, 8, len_limit);  // only if !use8
+            if (l > len_limit) l = len_limit;
         }
-        uint32_t l = valid ? mf_lcp(data, t.n, P, Q, len_limit) : 0;
         for (;;) {  // record breakers in lane order
             unsigned long long m = __ballot(valid && l > max_len);
             if (m == 0) break;
             const int f = __builtin_ctzll(m);
             const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
             const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)Q, f);
-            out[2 * n] = bl;
-            out[2 * n + 1] = P - bq - 1;
+            emit(n, bl, P - bq - 1);
             n++;
             max_len = bl;
             if (bl == len_limit) return n;  // lz_bin_tree.go:231-235
         }
-        if (__ballot(valid) != ~0ull || base <= 64) break;
+        if (__ballot(valid) != ~0ull || base - g4 <= 64) break;
     }
     if (qstar == kNone) return n;
 
     // ---- scan of the 8-gram group from Q* on
-    for (uint32_t base = r8;; base -= 64) {
-        bool valid = base > lane;
+    for (uint32_t base = r8; base > g8; base -= 64) {
+        bool valid = base > g8 + lane;
         uint32_t Q = 0, l = 0;
         if (valid) {
-            Q = t.ord8[base - 1 - lane];
+            const MfEnt e = t.ent8[base - 1 - lane];
+            Q = e.pos;
             valid = Q >= W;
-        }
-        if (valid) {
-            l = mf_lcp(data, t.n, P, Q, len_limit);
-            valid = l >= 8;  // still the same 8-gram
+            const uint64_t y = e.sig ^ pn8;
+            l = 8 + (y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8);
+            if (valid && l >= 16 && len_limit > 16) l = mf_extend(data, t.n, P, Q, 16, len_limit);
+            if (l > len_limit) l = len_limit;
         }
         for (;;) {
             unsigned long long m = __ballot(valid && l > max_len);
@@ -165,13 +195,12 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
             const int f = __builtin_ctzll(m);
             const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
             const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)Q, f);
-            out[2 * n] = bl;
-            out[2 * n + 1] = P - bq - 1;
+            emit(n, bl, P - bq - 1);
             n++;
             max_len = bl;
             if (bl == len_limit) return n;
         }
-        if (__ballot(valid) != ~0ull || base <= 64) break;
+        if (__ballot(valid) != ~0ull || base - g8 <= 64) break;
     }
     return n;
 }

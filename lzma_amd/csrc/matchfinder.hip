@@ -6,14 +6,19 @@
 //      first 8 bytes of every position;
 //   2. stable radix sorts of (key, position) -- rocPRIM device radix sort, the one
 //      library primitive used -- giving each bucket's positions in ascending order;
-//   3. scatter kernels: rank of every position in its bucket, previous position with
-//      the same hash-2 / hash-3 slot;
+//   3. table kernels: 16-byte entries (position, start of its bucket, 8 bytes of its
+//      text) in sorted order, and per position its rank in both tables and the
+//      previous position with the same hash-2 / hash-3 slot;
 //   4. the scan kernel (lzma_mf_core.hpp): one wave per position, 64 candidates per
-//      step, record breakers by ballot.  Run twice (count, then fill at the offsets
-//      of an exclusive scan) so that the output is ordered by position.
+//      step read as consecutive 16-byte entries, record breakers by ballot.  Each
+//      wave walks a run of consecutive positions and appends their pairs to a
+//      private page of a global arena (one atomic per 8192 pairs); a word per
+//      position records where its pairs are.
+//   5. (stand-alone entry point only) an exclusive scan of the counts and a gather
+//      put the pairs in position order.
 //
 // Roofline class: HBM (N input bytes read, 4N count bytes + 8 bytes per pair
-// written); the scan is latency- and issue-bound on gathers through L2.
+// written).
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -25,6 +30,8 @@
 namespace {
 
 using lz::kNone;
+using lz::MfEnt;
+using lz::MfInfo;
 
 enum { KEY2 = 2, KEY3 = 3, KEY4 = 4, KEY8 = 8 };
 
@@ -56,26 +63,50 @@ __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__
     }
 }
 
-// rank[ord[j]] = j
-__global__ __launch_bounds__(256) void mf_rank_kernel(const uint32_t *__restrict__ ord, uint32_t n,
-                                                      uint32_t *__restrict__ rank) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) rank[ord[j]] = j;
-}
-
-// prev[ord[j]] = ord[j-1] if it has the same key, else kNone
-__global__ __launch_bounds__(256) void mf_prev_kernel(const uint32_t *__restrict__ ord,
-                                                      const uint32_t *__restrict__ skey, uint32_t n,
-                                                      uint32_t *__restrict__ prev) {
+// head[j] = j if entry j starts a new key group, else 0 (max-scanned into group starts)
+template <class K>
+__global__ __launch_bounds__(256) void mf_head_kernel(const K *__restrict__ skey, uint32_t n,
+                                                      uint32_t *__restrict__ head) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
-        prev[ord[j]] = (j > 0 && skey[j - 1] == skey[j]) ? ord[j - 1] : kNone;
+        head[j] = (j > 0 && skey[j - 1] != skey[j]) ? j : 0;
 }
 
-unsigned grid_for(uint32_t n, unsigned block, unsigned max_blocks = 256 * 32) {
-    unsigned g = (n + block - 1) / block;
+// ent[j] = {ord[j], gstart[j], 8 bytes at data[ord[j] + sig_off]};  rank of ord[j] = j
+template <int WHICH>
+__global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__ data, uint32_t n,
+                                                     const uint32_t *__restrict__ ord,
+                                                     const uint32_t *__restrict__ gstart,
+                                                     uint32_t sig_off, MfEnt *__restrict__ ent,
+                                                     MfInfo *__restrict__ info) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t p = ord[j];
+        MfEnt e;
+        e.pos = p;
+        e.gstart = gstart[j];
+        e.sig = lz::mf_load8(data, n, p + sig_off);
+        ent[j] = e;
+        if (WHICH == 4) info[p].rank4 = j; else info[p].rank8 = j;
+    }
+}
+
+// prev of ord[j] = ord[j-1] if it has the same key, else kNone
+template <int WHICH>
+__global__ __launch_bounds__(256) void mf_prev_kernel(const uint32_t *__restrict__ ord,
+                                                      const uint32_t *__restrict__ skey, uint32_t n,
+                                                      MfInfo *__restrict__ info) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t v = (j > 0 && skey[j - 1] == skey[j]) ? ord[j - 1] : kNone;
+        if (WHICH == 2) info[ord[j]].prev2 = v; else info[ord[j]].prev3 = v;
+    }
+}
+
+unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 256 * 32) {
+    uint64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
-    return g < max_blocks ? g : max_blocks;
+    return (unsigned)(g < max_blocks ? g : max_blocks);
 }
 
 template <class K>
@@ -93,32 +124,104 @@ int sort_by_key(K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n, unsigne
     return LZMA_AMD_OK;
 }
 
+int max_scan(uint32_t *io, uint32_t n, hipStream_t st) {
+    size_t bytes = 0;
+    LZ_HIP(rocprim::inclusive_scan(nullptr, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
+    lzh::DevBuf temp;
+    LZ_HIP(temp.alloc(bytes));
+    LZ_HIP(rocprim::inclusive_scan(temp.p, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
+    LZ_HIP(hipStreamSynchronize(st));
+    return LZMA_AMD_OK;
+}
+
 unsigned bits_of(uint32_t mask) {
     unsigned b = 0;
     while (b < 32 && (mask >> b) != 0) b++;
     return b ? b : 1;
 }
 
-// Stand-alone finder: one wave per position.  FILL == false: counts only.
-template <bool FILL>
-__global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, uint32_t n,
-                                                      uint32_t *__restrict__ counts,
-                                                      const uint64_t *__restrict__ offsets,
-                                                      uint32_t *__restrict__ pairs, uint64_t pairs_cap) {
-    __shared__ uint32_t s_out[4][2 * (lz::kMatchMax + 1) + 2];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t nwaves = gridDim.x * 4;
-    uint32_t *out = s_out[wave];
-    for (uint32_t P = blockIdx.x * 4 + wave; P < n; P += nwaves) {
-        const uint32_t c = lz::mf_find(t, P, 0u, n, out, lane);
-        if (!FILL) {
-            if (lane == 0) counts[P] = c;
-        } else {
-            const uint64_t off = offsets[P];
-            if (off + c <= pairs_cap)
-                for (uint32_t k = lane; k < 2 * c; k += 64) pairs[2 * off + k] = out[k];
+constexpr uint32_t kRun = 256;  // consecutive positions handled by one wave before it moves on
+
+// ctrl[0] = next free arena pair index, ctrl[1] = overflow flag, ctrl[2] = pairs emitted
+__global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+                                                      uint64_t base, uint64_t j0, uint32_t njobs,
+                                                      uint64_t *__restrict__ meta,
+                                                      uint32_t *__restrict__ arena, uint64_t arena_pairs,
+                                                      unsigned long long *ctrl) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t n = t.n;
+    const uint32_t nruns = (n + kRun - 1) / kRun;
+    uint64_t cursor = 0, page_end = 0;  // wave-private arena page
+    uint64_t emitted = 0;
+    bool overflow = false;
+    for (uint32_t run = wave; run < nruns; run += nwaves) {
+        const uint32_t p_begin = run * kRun;
+        const uint32_t p_end = p_begin + kRun < n ? p_begin + kRun : n;
+        // job containing p_begin: last j with job_off[j] - base <= p_begin
+        uint32_t lo = 0, hi = njobs;  // invariant: off[lo] <= p_begin < off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (job_off[j0 + mid] - base <= p_begin) lo = mid; else hi = mid;
+        }
+        uint32_t job = lo;
+        uint32_t js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
+        for (uint32_t P = p_begin; P < p_end; P++) {
+            while (P >= je) {  // empty jobs are skipped
+                job++;
+                js = je;
+                je = (uint32_t)(job_off[j0 + job + 1] - base);
+            }
+            if (page_end - cursor < lz::kMatchMax + 1 && !overflow) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctrl[0], (unsigned long long)lzh::kMfPagePairs);
+                b = __shfl(b, 0);
+                if (b + lzh::kMfPagePairs > arena_pairs) {
+                    overflow = true;
+                } else {
+                    cursor = b;
+                    page_end = b + lzh::kMfPagePairs;
+                }
+            }
+            uint32_t *dst = arena + 2 * cursor;
+            const bool ovf = overflow;
+            auto emit = [&](uint32_t k, uint32_t len, uint32_t dist) {
+                if (lane == 0 && !ovf) {
+                    dst[2 * k] = len;
+                    dst[2 * k + 1] = dist;
+                }
+            };
+            const uint32_t c = lz::mf_find(t, P, js, je, emit, lane);
+            if (lane == 0) meta[P] = lz::mf_meta(cursor, c);
+            if (!overflow) cursor += c;
+            emitted += c;
         }
     }
+    if (lane == 0) {
+        if (overflow) atomicAdd(&ctrl[1], 1ull);
+        atomicAdd(&ctrl[2], (unsigned long long)emitted);
+    }
+}
+
+// Stand-alone entry point: pairs of position P to out[offsets[P]...] in position order.
+__global__ __launch_bounds__(256) void mf_gather_kernel(const uint64_t *__restrict__ meta,
+                                                        const uint32_t *__restrict__ arena, uint32_t n,
+                                                        const uint64_t *__restrict__ offsets,
+                                                        uint32_t *__restrict__ pairs, uint64_t pairs_cap) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t P = blockIdx.x * blockDim.x + threadIdx.x; P < n; P += stride) {
+        const uint64_t m = meta[P], src = lz::mf_meta_off(m), dst = offsets[P];
+        const uint32_t c = lz::mf_meta_count(m);
+        if (dst + c > pairs_cap) continue;
+        for (uint32_t k = 0; k < 2 * c; k++) pairs[2 * dst + k] = arena[2 * src + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_counts_kernel(const uint64_t *__restrict__ meta, uint32_t n,
+                                                        uint32_t *__restrict__ counts) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t P = blockIdx.x * blockDim.x + threadIdx.x; P < n; P += stride)
+        counts[P] = lz::mf_meta_count(meta[P]);
 }
 
 }  // namespace
@@ -128,67 +231,102 @@ namespace lzh {
 int MfWorkspace::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb,
                        hipStream_t st) {
     const uint32_t mask = lz::bt4_hash_mask(dict_size);
-    const size_t w = (size_t)(n ? n : 1) * sizeof(uint32_t);
-    LZ_HIP(ord4.alloc(w));
-    LZ_HIP(skey4.alloc(w));
-    LZ_HIP(rank4.alloc(w));
-    LZ_HIP(ord8.alloc(w));
-    LZ_HIP(rank8.alloc(w));
-    LZ_HIP(prev2.alloc(w));
-    LZ_HIP(prev3.alloc(w));
+    const size_t n1 = n ? n : 1;
+    LZ_HIP(ent4.alloc(n1 * sizeof(MfEnt)));
+    LZ_HIP(ent8.alloc(n1 * sizeof(MfEnt)));
+    LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
     view.data = d_data;
     view.n = n;
-    view.ord4 = ord4.as<uint32_t>();
-    view.skey4 = skey4.as<uint32_t>();
-    view.rank4 = rank4.as<uint32_t>();
-    view.ord8 = ord8.as<uint32_t>();
-    view.rank8 = rank8.as<uint32_t>();
-    view.prev2 = prev2.as<uint32_t>();
-    view.prev3 = prev3.as<uint32_t>();
+    view.ent4 = ent4.as<MfEnt>();
+    view.ent8 = ent8.as<MfEnt>();
+    view.info = info.as<MfInfo>();
     view.dict = dict_size;
     view.fb = fb;
     view.use8 = fb >= 8;
     if (n == 0) return LZMA_AMD_OK;
 
-    DevBuf kin, kout, vout;  // temporaries sized for the 64-bit keys
-    LZ_HIP(kin.alloc((size_t)n * 8));
-    LZ_HIP(kout.alloc((size_t)n * 8));
-    LZ_HIP(vout.alloc(w));
+    DevBuf kin, kout, vout, grp;  // temporaries sized for the 64-bit keys
+    LZ_HIP(kin.alloc(n1 * 8));
+    LZ_HIP(kout.alloc(n1 * 8));
+    LZ_HIP(vout.alloc(n1 * 4));
+    LZ_HIP(grp.alloc(n1 * 4));
     const unsigned g = grid_for(n, 256);
     int rc;
     // hash-4 buckets
     hipLaunchKernelGGL((mf_key_kernel<KEY4, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, mask,
                        kin.as<uint32_t>());
-    if ((rc = sort_by_key(kin.as<uint32_t>(), skey4.as<uint32_t>(), ord4.as<uint32_t>(), n,
+    if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n,
                           bits_of(mask), st)))
         return rc;
-    hipLaunchKernelGGL(mf_rank_kernel, dim3(g), dim3(256), 0, st, ord4.as<uint32_t>(), n,
-                       rank4.as<uint32_t>());
+    hipLaunchKernelGGL(mf_head_kernel<uint32_t>, dim3(g), dim3(256), 0, st, kout.as<uint32_t>(), n,
+                       grp.as<uint32_t>());
+    if ((rc = max_scan(grp.as<uint32_t>(), n, st))) return rc;
+    hipLaunchKernelGGL(mf_ent_kernel<4>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
+                       grp.as<uint32_t>(), 0u, ent4.as<MfEnt>(), info.as<MfInfo>());
     // 8-gram groups
     if (view.use8) {
         hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            kin.as<uint64_t>());
-        if ((rc = sort_by_key(kin.as<uint64_t>(), kout.as<uint64_t>(), ord8.as<uint32_t>(), n, 64, st)))
+        if ((rc = sort_by_key(kin.as<uint64_t>(), kout.as<uint64_t>(), vout.as<uint32_t>(), n, 64, st)))
             return rc;
-        hipLaunchKernelGGL(mf_rank_kernel, dim3(g), dim3(256), 0, st, ord8.as<uint32_t>(), n,
-                           rank8.as<uint32_t>());
+        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, kout.as<uint64_t>(), n,
+                           grp.as<uint32_t>());
+        if ((rc = max_scan(grp.as<uint32_t>(), n, st))) return rc;
+        hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
+                           grp.as<uint32_t>(), 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        kin.as<uint32_t>());
     if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 16, st)))
         return rc;
-    hipLaunchKernelGGL(mf_prev_kernel, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
-                       kout.as<uint32_t>(), n, prev3.as<uint32_t>());
+    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
+                       kout.as<uint32_t>(), n, info.as<MfInfo>());
     hipLaunchKernelGGL((mf_key_kernel<KEY2, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        kin.as<uint32_t>());
     if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 10, st)))
         return rc;
-    hipLaunchKernelGGL(mf_prev_kernel, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
-                       kout.as<uint32_t>(), n, prev2.as<uint32_t>());
+    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
+                       kout.as<uint32_t>(), n, info.as<MfInfo>());
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipStreamSynchronize(st));  // temporaries go out of scope
     return LZMA_AMD_OK;
+}
+
+int MfWorkspace::scan(const uint64_t *d_job_off, uint64_t base, uint64_t j0, uint32_t njobs,
+                      hipStream_t st, uint64_t *total_pairs) {
+    const uint32_t n = view.n;
+    if (total_pairs) *total_pairs = 0;
+    if (n == 0 || njobs == 0) return LZMA_AMD_OK;
+    const uint32_t nruns = (n + kRun - 1) / kRun;
+    unsigned blocks = (nruns + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const uint64_t nwaves = (uint64_t)blocks * 4;
+    LZ_HIP(meta.alloc((size_t)n * 8));
+    LZ_HIP(ctrl.alloc(3 * 8));
+    uint64_t want = (uint64_t)n * 5 + nwaves * kMfPagePairs;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        if (arena_pairs < want) {
+            arena.release();
+            LZ_HIP(arena.alloc(want * 8));
+            arena_pairs = want;
+        }
+        LZ_HIP(hipMemsetAsync(ctrl.p, 0, 3 * 8, st));
+        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks), dim3(256), 0, st, view, d_job_off, base, j0,
+                           njobs, meta.as<uint64_t>(), arena.as<uint32_t>(), arena_pairs,
+                           ctrl.as<unsigned long long>());
+        LZ_HIP(hipGetLastError());
+        unsigned long long h[3];
+        LZ_HIP(hipMemcpyAsync(h, ctrl.p, sizeof h, hipMemcpyDeviceToHost, st));
+        LZ_HIP(hipStreamSynchronize(st));
+        if (h[1] == 0) {
+            if (total_pairs) *total_pairs = h[2];
+            return LZMA_AMD_OK;
+        }
+        // the emitted count is exact even when the arena overflowed
+        want = h[2] + h[2] / 16 + nwaves * kMfPagePairs;
+    }
+    return fail(LZMA_AMD_ERR_NOMEM, "match finder arena kept overflowing");
 }
 
 }  // namespace lzh
@@ -216,14 +354,21 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     lzh::MfWorkspace ws;
     int rc = ws.build(d_data, N, dict_size, fb, st);
     if (rc) return rc;
-    lzh::DevBuf offs;  // n+1 exclusive offsets
-    uint64_t *d_off = d_offsets;
-    LZ_HIP(offs.alloc((n + 1) * 8));
-    const unsigned g = grid_for(N, 4, 256 * 64);
+    lzh::DevBuf joff;
+    const uint64_t h_joff[2] = {0, n};
+    LZ_HIP(joff.alloc(16));
+    LZ_HIP(hipMemcpyAsync(joff.p, h_joff, 16, hipMemcpyHostToDevice, st));
+    uint64_t total = 0;
     t_scan.start(st);
-    hipLaunchKernelGGL(mf_scan_kernel<false>, dim3(g), dim3(256), 0, st, ws.view, N, d_counts,
-                       (const uint64_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
-    {
+    rc = ws.scan(joff.as<uint64_t>(), 0, 0, 1, st, &total);
+    t_scan.stop();
+    if (rc) return rc;
+    const unsigned g = grid_for(N, 256);
+    hipLaunchKernelGGL(mf_counts_kernel, dim3(g), dim3(256), 0, st, ws.d_meta(), N, d_counts);
+    LZ_HIP(hipMemcpyAsync(d_total_pairs, &total, 8, hipMemcpyHostToDevice, st));
+    lzh::DevBuf offs;
+    if ((d_pairs && total <= pairs_cap) || d_offsets) {
+        LZ_HIP(offs.alloc(n * 8));
         size_t bytes = 0;
         auto in = rocprim::make_transform_iterator(d_counts, [] __device__(uint32_t c) { return (uint64_t)c; });
         LZ_HIP(rocprim::exclusive_scan(nullptr, bytes, in, offs.as<uint64_t>(), (uint64_t)0, n,
@@ -233,21 +378,11 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
         LZ_HIP(rocprim::exclusive_scan(temp.p, bytes, in, offs.as<uint64_t>(), (uint64_t)0, n,
                                        rocprim::plus<uint64_t>(), st));
         LZ_HIP(hipStreamSynchronize(st));
+        if (d_offsets) LZ_HIP(hipMemcpyAsync(d_offsets, offs.p, n * 8, hipMemcpyDeviceToDevice, st));
+        if (d_pairs && total <= pairs_cap)
+            hipLaunchKernelGGL(mf_gather_kernel, dim3(g), dim3(256), 0, st, ws.d_meta(), ws.d_arena(), N,
+                               offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap);
     }
-    // total = offs[n-1] + counts[n-1]
-    uint64_t last_off = 0;
-    uint32_t last_cnt = 0;
-    LZ_HIP(hipMemcpyAsync(&last_off, offs.as<uint64_t>() + (n - 1), 8, hipMemcpyDeviceToHost, st));
-    LZ_HIP(hipMemcpyAsync(&last_cnt, d_counts + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    LZ_HIP(hipStreamSynchronize(st));
-    const uint64_t total = last_off + last_cnt;
-    LZ_HIP(hipMemcpyAsync(d_total_pairs, &total, 8, hipMemcpyHostToDevice, st));
-    if (d_off) LZ_HIP(hipMemcpyAsync(d_off, offs.p, n * 8, hipMemcpyDeviceToDevice, st));
-    if (d_pairs && total <= pairs_cap) {
-        hipLaunchKernelGGL(mf_scan_kernel<true>, dim3(g), dim3(256), 0, st, ws.view, N, d_counts,
-                           offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap);
-    }
-    t_scan.stop();
     t_all.stop();
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipStreamSynchronize(st));
