@@ -6,7 +6,10 @@ raises -- there is no CPU fallback anywhere in this package.
 import ctypes as C
 from pathlib import Path
 
-_SO = Path(__file__).resolve().parent / "liblzma_amd.so"
+import os
+
+# LZMA_AMD_LIB selects another build of the same library (diagnostic builds)
+_SO = Path(os.environ.get("LZMA_AMD_LIB") or Path(__file__).resolve().parent / "liblzma_amd.so")
 
 OK, ERR_HEADER, ERR_STREAM, ERR_TRUNCATED, ERR_OUT_CAP, ERR_ARG, ERR_NOMEM, ERR_HIP, \
     ERR_UNSUPPORTED = range(9)

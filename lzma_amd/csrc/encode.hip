@@ -2,15 +2,20 @@
 // stream, one 64-lane wavefront (= one workgroup) per chunk.
 //
 // Replaces encoder.encoder() of the reference (lzma_encoder.go:989-1107) run once
-// per chunk.  The optimal parse and the range coder (lzma_enc_core.hpp) run with
-// wave-uniform values; the probability models, the 16-bit price tables and the
-// current match list live in LDS (about 26 KiB per chunk at lc3 lp0 pb2, six
-// chunks resident per CU); the optimum table sits in HBM.  Match lists come from
-// the exhaustive BT4 finder (lzma_mf_core.hpp), evaluated by the same wave with all
-// 64 lanes whenever the parse asks for a position's matches.
+// per chunk.  Two phases per batch of chunks:
+//   1. the exhaustive BT4 finder (matchfinder.hip) computes the match list of every
+//      position of every chunk at full-chip throughput;
+//   2. encode_kernel runs the optimal parse and the range coder (lzma_enc_core.hpp),
+//      one wave per chunk, reading the lists as it goes.
+// A chunk's wave is a long dependent chain, so throughput comes from how many chains
+// a CU holds: the state kept in LDS is cut to 20 KiB (non-literal models, 16-bit
+// price tables, a 128-entry window of the optimum table, the current match list),
+// eight chunks per CU; the literal models (12 KiB at lc3) sit in HBM behind the L2,
+// which costs a chain about 2 % and buys twice the resident chains.
 //
 // Roofline class: HBM in principle (N bytes in, C bytes out per chunk);
 // serial-dependency-bound in practice.
+#include <type_traits>
 #include <vector>
 
 #include "lzma_enc_core.hpp"
@@ -18,43 +23,61 @@
 
 namespace {
 
-constexpr uint32_t kLitLdsLog = 3;
-constexpr uint32_t kMdistWords = 2 * (lz::kMatchMax + 1) + 2;
 
-// Match list of a chunk position, read from the finder's results.
+// Match list of a chunk position, read from the finder's results.  The parse asks
+// for consecutive positions almost all the time, so the words of the next position's
+// list (one per lane) and the result word of the position after it are requested
+// one call ahead and are usually there when needed.
 struct MfFunctor {
     const uint64_t *meta;
     const uint32_t *arena;
-    uint32_t job_start, lane;
-    __device__ uint32_t operator()(uint32_t pos, uint32_t *out) const {
-        const uint64_t m = meta[job_start + pos];
+    uint32_t job_start, lane, n_total;
+    uint32_t pf_pos;
+    uint64_t pf_meta, pf_meta2;
+    uint32_t pf_word;
+    __device__ uint32_t operator()(uint32_t pos, LZ_LDS uint32_t *out) {
+        const bool hit = pos == pf_pos;
+        const uint64_t m = hit ? pf_meta : meta[job_start + pos];
         const uint32_t c = lz::mf_meta_count(m);
-        const uint32_t *src = arena + 2 * lz::mf_meta_off(m);
-        for (uint32_t k = lane; k < 2 * c; k += 64) out[k] = src[k];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (hit && 2 * c <= 64) {
+            if (lane < 2 * c) out[lane] = pf_word;
+        } else {
+            const uint32_t *src = arena + 2 * lz::mf_meta_off(m);
+            for (uint32_t k = lane; k < 2 * c; k += 64) out[k] = src[k];
+        }
+        uint32_t g1 = job_start + pos + 1, g2 = job_start + pos + 2;
+        if (g1 >= n_total) g1 = n_total - 1;
+        if (g2 >= n_total) g2 = n_total - 1;
+        const uint64_t m1 = hit ? pf_meta2 : meta[g1];
+        const uint32_t c1 = lz::mf_meta_count(m1);
+        uint32_t w = 0;
+        if (2 * c1 <= 64 && lane < 2 * c1) w = arena[2 * lz::mf_meta_off(m1) + lane];
+        pf_word = w;
+        pf_meta = m1;
+        pf_meta2 = meta[g2];
+        pf_pos = pos + 1;
         return c;
     }
 };
 
 struct LdsLayout {
-    uint32_t probs, prices, pp, mdist, small, total;  // byte offsets
+    uint32_t probs, prices, pp, opt, small, total;  // byte offsets
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t lc, uint32_t lp, uint32_t pb, bool lit_lds) {
+__host__ __device__ inline LdsLayout lds_layout(uint32_t pb) {
     LdsLayout l;
-    uint32_t nprobs = lz::kNumBaseProbs + (lit_lds ? (0x300u << (lc + lp)) : 0);
+    uint32_t nprobs = lz::kNumBaseProbs;
     l.probs = 0;
     l.prices = (l.probs + nprobs * 2 + 15) & ~15u;
     l.pp = (l.prices + lz::price_layout(pb).total * 2 + 15) & ~15u;
-    l.mdist = l.pp + 512 * 2;
-    l.small = l.mdist + kMdistWords * 4;
+    l.opt = l.pp + 512 * 2;
+    l.small = l.opt + 8 * lz::kOptLds * 4;
     l.total = l.small + lz::kEncSmallWords * 4;
     return l;
 }
 
 // Chunks [c0, c0 + nchunks) of the call; their bytes start at data offset
 // in_off[c] - base inside t.data.
-template <bool LIT_LDS>
-__global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ data,
+__global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
                                                     const uint64_t *__restrict__ mf_meta,
                                                     const uint32_t *__restrict__ mf_arena,
                                                     const uint64_t *__restrict__ in_off,
@@ -62,18 +85,19 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
                                                     lz::EncParams ep, uint8_t *__restrict__ out,
                                                     const uint64_t *__restrict__ out_off,
                                                     uint64_t *__restrict__ out_sizes,
-                                                    int32_t *__restrict__ status, lz::Opt *opt_scratch,
+                                                    int32_t *__restrict__ status, lz::OptG *opt_scratch,
                                                     lz::prob_t *lit_scratch, uint64_t lit_stride) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
-    const LdsLayout L = lds_layout(ep.lc, ep.lp, ep.pb, LIT_LDS);
-    lz::prob_t *probs = reinterpret_cast<lz::prob_t *>(smem + L.probs);
-    uint16_t *prices = reinterpret_cast<uint16_t *>(smem + L.prices);
-    uint16_t *pp = reinterpret_cast<uint16_t *>(smem + L.pp);
-    uint32_t *mdist = reinterpret_cast<uint32_t *>(smem + L.mdist);
-    uint32_t *small = reinterpret_cast<uint32_t *>(smem + L.small);
+    const LdsLayout L = lds_layout(ep.pb);
+    LZ_LDS uint8_t *sm = (LZ_LDS uint8_t *)smem;
+    LZ_LDS lz::prob_t *probs = (LZ_LDS lz::prob_t *)(sm + L.probs);
+    LZ_LDS uint16_t *prices = (LZ_LDS uint16_t *)(sm + L.prices);
+    LZ_LDS uint16_t *pp = (LZ_LDS uint16_t *)(sm + L.pp);
+    LZ_LDS uint32_t *optl = (LZ_LDS uint32_t *)(sm + L.opt);
+    LZ_LDS uint32_t *small = (LZ_LDS uint32_t *)(sm + L.small);
     const uint32_t lit_n = 0x300u << (ep.lc + ep.lp);
-    lz::build_prob_prices(pp, lane, 64u);
+    lz::build_prob_prices((uint16_t *)pp, lane, 64u);
 
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint64_t chunk = c0 + c;
@@ -88,29 +112,41 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         }
         __syncthreads();
         for (uint32_t i = lane; i < lz::kNumBaseProbs; i += 64) probs[i] = lz::kProbInit;
-        lz::prob_t *lit;
-        if (LIT_LDS) {
-            lit = probs + lz::P_LIT;
-        } else {
-            lit = lit_scratch + (uint64_t)blockIdx.x * lit_stride;
-        }
+        lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_stride;
         for (uint32_t i = lane; i < lit_n; i += 64) lit[i] = lz::kProbInit;
         __syncthreads();
 
-        lz::Encoder<MfFunctor, lz::prob_t, lz::prob_t, uint16_t> e;
+        lz::Encoder<MfFunctor, lz::prob_t *> e;
         e.data = data + jb;
         e.n = je - jb;
+        e.readable = data_n - jb;
         e.probs = probs;
         e.lit = lit;
         e.prices = prices;
         e.pp = pp;
-        e.opt = opt_scratch + (uint64_t)blockIdx.x * lz::kNumOpts;
-        e.mdist = mdist;
+        e.o_price = optl;
+        e.o_back = optl + lz::kOptLds;
+        e.o_pp = optl + 2 * lz::kOptLds;
+        e.o_back2 = optl + 3 * lz::kOptLds;
+        e.o_backs = optl + 4 * lz::kOptLds;
+        e.opt_g = opt_scratch + (uint64_t)blockIdx.x * lz::kNumOpts;
+        e.lane_id = lane;
         e.out = out + ob + lz::kHeaderSize;
         e.out_cap = oe - ob - lz::kHeaderSize;
-        e.mf = MfFunctor{mf_meta, mf_arena, jb, lane};
+        e.mf = MfFunctor{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
         e.ep = ep;
+#if defined(LZ_PROFILE)
+        for (int i = 0; i < 12; i++) e.prof[i] = 0;
+        e.prof_last = __builtin_readcyclecounter();
+#endif
         e.run(small);
+#if defined(LZ_PROFILE)
+        if (lane == 0 && blockIdx.x == 0)
+            printf("PROF chunk n=%u: mf %llu | stateA %llu | round %llu | mid %llu | apply %llu | loopctl %llu | getopt_other %llu | emit %llu\n",
+                   e.n, (unsigned long long)e.prof[0], (unsigned long long)e.prof[1], (unsigned long long)e.prof[2],
+                   (unsigned long long)e.prof[3], (unsigned long long)e.prof[4], (unsigned long long)e.prof[5],
+                   (unsigned long long)e.prof[6], (unsigned long long)e.prof[7]);
+#endif
         if (lane == 0) {
             lz::write_header(out + ob, ep, ep.eos ? -1 : (int64_t)e.n);
             status[chunk] = e.overflow ? lz::ST_OUT_CAP : lz::ST_OK;
@@ -160,8 +196,8 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     }
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
-    const bool lit_lds = p->lc + p->lp <= kLitLdsLog;
-    const LdsLayout L = lds_layout(p->lc, p->lp, p->pb, lit_lds);
+    const LdsLayout L = lds_layout(p->pb);
+    const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
 
     float ms_finder = 0.f, ms_coder = 0.f;
     size_t c0 = 0;
@@ -180,24 +216,21 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         rc = ws.scan(d_in_off, base, c0, nchunks, st, &total_pairs);
         if (rc) return rc;
         t_mf.stop();
+        // resident workgroups: eight per CU, fewer if the literal models are large
         unsigned grid = nchunks;
-        const unsigned max_grid = lit_lds ? 256u * 16u : 512u;
+        unsigned max_grid = 256u * 8u;
+        const uint64_t lit_budget = 2ull << 30;
+        if ((uint64_t)max_grid * lit_stride * sizeof(lz::prob_t) > lit_budget)
+            max_grid = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
         if (grid > max_grid) grid = max_grid;
         lzh::DevBuf opt, lit;
-        LZ_HIP(opt.alloc((size_t)grid * lz::kNumOpts * sizeof(lz::Opt)));
-        const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
-        if (!lit_lds) LZ_HIP(lit.alloc((size_t)grid * lit_stride * sizeof(lz::prob_t)));
+        LZ_HIP(opt.alloc((size_t)grid * lz::kNumOpts * sizeof(lz::OptG)));
+        LZ_HIP(lit.alloc((size_t)grid * lit_stride * sizeof(lz::prob_t)));
         t_enc.start(st);
-        if (lit_lds)
-            hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(64), L.total, st, d_in + base, ws.d_meta(),
-                               ws.d_arena(), d_in_off,
-                               base, (uint64_t)c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
-                               opt.as<lz::Opt>(), (lz::prob_t *)nullptr, (uint64_t)0);
-        else
-            hipLaunchKernelGGL(encode_kernel<false>, dim3(grid), dim3(64), L.total, st, d_in + base, ws.d_meta(),
-                               ws.d_arena(), d_in_off,
-                               base, (uint64_t)c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
-                               opt.as<lz::Opt>(), lit.as<lz::prob_t>(), lit_stride);
+        hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), L.total, st, d_in + base, nbytes,
+                           ws.d_meta(), ws.d_arena(), d_in_off, base, (uint64_t)c0, nchunks, ep, d_out,
+                           d_out_off, d_out_sizes, d_status, opt.as<lz::OptG>(), lit.as<lz::prob_t>(),
+                           lit_stride);
         t_enc.stop();
         LZ_HIP(hipGetLastError());
         LZ_HIP(hipStreamSynchronize(st));

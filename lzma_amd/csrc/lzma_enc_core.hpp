@@ -1,44 +1,92 @@
-// Serial core of the per-chunk LZMA encoder: price-optimal parse + range coder.
+// Core of the per-chunk LZMA encoder: price-optimal parse + range coder.
 //
-// Behaviour follows the reference encoder: getOptimum/backward
+// Results follow the reference encoder exactly: getOptimum/backward
 // (lzma_encoder.go:331-797), codeOneBlock/flush/writeEndMarker (:836-978), the
 // price tables (:294-329, :801-834), the length coder with its cached price table
 // (lzma_len_coder.go:48-126), the literal coder (lzma_lit_coder.go:47-102), the
 // bit trees (range_bit_tree_coder.go:53-117) and the range encoder
 // (range_coder.go:131-246).
 //
-// What differs is where things live and who finds matches:
+// What differs is how the work is laid out for a 64-lane wavefront that owns one
+// chunk:
 //   * the match finder is a functor `mf(pos, pairs)` that returns the match list
 //     of any position directly (the lists of the exhaustive BT4 finder are a pure
 //     function of the data, so skipped positions cost nothing);
-//   * models and price tables are meant to sit in LDS, prices are 16-bit, the
-//     optimum table (4096 entries) sits in HBM behind the L2;
+//   * one step of the parse (one position `cur` of getOptimum's main loop) is two
+//     lane-parallel phases instead of nested loops:
+//       round:   every lane runs the same code on its own task -- lanes 0-3 measure a
+//                rep match and price its "rep + literal + rep0" continuation, one lane
+//                prices the literal, the others price the "match + literal + rep0"
+//                continuation of one pair of the match list each;
+//       apply:   one lane per optimum-table entry cur+2.. applies, in the reference's
+//                order and with its strict comparisons, every candidate that targets
+//                that entry.  (Candidate prices never depend on the entries they
+//                update, and for any entry the reference visits its candidates in a
+//                fixed order -- continuation of literal, then per rep its lengths and
+//                its continuation, then match continuations by pair, then the plain
+//                match length -- so applying them per entry gives the same table.)
+//   * models, price tables (16-bit) and the first kOptLds entries of the optimum
+//     table live in LDS (structure-of-arrays, so the apply phase is bank-conflict
+//     free); the rest of the 4096 entries sits in HBM and is almost never touched;
+//   * match lengths are measured eight bytes at a time;
 //   * getPosSlot is computed with a count-leading-zeros instead of a 2 KiB table.
 //
-// Execution model on the GPU: one wavefront per chunk, all lanes executing this
-// code with identical values.  The same source compiles on the host
-// (LZ_HOSTSIM) for tests.
+// Code outside LZ_PAR_BEGIN/LZ_PAR_END is executed by all lanes with identical
+// values (so the compiler keeps it on the scalar unit); code inside runs once per
+// lane and only communicates through memory.  The same source compiles on the host
+// (LZ_HOSTSIM), where a parallel section is a loop over the 64 lanes.
 #pragma once
 #include "lzma_common.hpp"
 
 namespace lz {
 
-constexpr uint32_t kEncSmallWords = 12 + 2 * kPosStatesMax + kNumFullDist;
+constexpr uint32_t kLanes = 64;
+#ifndef LZ_OPT_LDS
+#define LZ_OPT_LDS 128
+#endif
+constexpr uint32_t kOptLds = LZ_OPT_LDS;     // optimum-table entries kept in LDS
+constexpr uint32_t kLaMax = 5 + kMatchMax + 1;  // continuation records: literal, 4 reps, pairs
+constexpr uint32_t kMdistWords = 2 * (kMatchMax + 1) + 2;
+// uint32 words of caller-provided scratch besides the tables (see Encoder::bind_small)
+constexpr uint32_t kEncSmallWords = 64 + 2 * kPosStatesMax + kNumFullDist + 2 * kLaMax + kMdistWords;
+
+// LZ_LDS qualifies pointers into LDS, so that their accesses are ds_* instructions
+// and can never be merged with global accesses into flat ones.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define LZ_LDS __attribute__((address_space(3)))
+#else
+#define LZ_LDS
+#endif
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define LZ_PAR_BEGIN(L) { const uint32_t L = lane_id;
+#define LZ_PAR_END } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#else
+#define LZ_PAR_BEGIN(L) for (uint32_t L = 0; L < kLanes; L++) {
+#define LZ_PAR_END }
+#endif
+
+// Section timing for diagnostic builds (-DLZ_PROFILE): LZ_LAP(i) charges the cycles since
+// the previous lap to section i.  Compiled out otherwise.
+#if defined(LZ_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define LZ_LAP(i) { const uint64_t t_ = __builtin_readcyclecounter(); prof[i] += t_ - prof_last; prof_last = t_; }
+#else
+#define LZ_LAP(i)
+#endif
 
 struct EncParams {
     uint32_t fb, lc, lp, pb, dict_size, dist_table_size, eos;
 };
 
-// One entry of the optimum table (`optimal`, lzma_encoder.go:167-181).
-struct Opt {
-    uint32_t price, back_prev, back_prev2;
-    uint32_t backs[4];
-    uint16_t pos_prev, pos_prev2;
-    uint8_t state, prev1_is_char, prev2, pad;
+// Optimum-table entry beyond the LDS window (`optimal`, lzma_encoder.go:167-181).
+// pp packs posPrev (bits 0-11), posPrev2 (12-23), state (24-27), prev1IsChar (28),
+// prev2 (29).
+struct OptG {
+    uint32_t price, back, pp, back2, backs[4];
 };
+constexpr uint32_t kPpPrev1 = 1u << 28, kPpPrev2 = 1u << 29;
 
-// Price of one bit, range_coder.go:222-246.  The 512-entry table is built by
-// build_prob_prices() below.
+// Price of one bit, range_coder.go:222-246.
 LZ_HD void build_prob_prices(uint16_t *pp, uint32_t lane, uint32_t nlanes) {
     for (uint32_t j = lane; j < 512; j += nlanes) {
         if (j == 0) {
@@ -75,22 +123,36 @@ LZ_HD PriceLayout price_layout(uint32_t pb) {
     return l;
 }
 
-template <class MF, class PT, class LT, class WT>
+LZ_HD uint64_t enc_load8(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+template <class MF, class LP>
 struct Encoder {
+    typedef LZ_LDS prob_t *PP;
+    typedef LZ_LDS uint32_t *U32P;
+    typedef uint16_t WT;
     // ---- memory the caller provides ----
     const uint8_t *data;  // chunk bytes
     uint32_t n;           // chunk length
-    PT *probs;            // kNumBaseProbs models
-    LT *lit;              // 0x300 << (lc+lp) literal models
-    WT *prices;           // price_layout(pb).total entries
-    const WT *pp;         // 512-entry bit-price table
-    Opt *opt;             // kNumOpts entries
-    uint32_t *mdist;      // 2 * (kMatchMax + 1) words: current match list (len, dist) pairs
+    uint32_t readable;    // bytes that may be read starting at data (>= n)
+    PP probs;             // kNumBaseProbs models
+    LP lit;               // 0x300 << (lc+lp) literal models (LDS or HBM)
+    LZ_LDS WT *prices;    // price_layout(pb).total entries
+    const LZ_LDS WT *pp;  // 512-entry bit-price table
+    U32P o_price, o_back, o_pp, o_back2, o_backs;  // kOptLds entries each (o_backs: x4)
+    OptG *opt_g;          // kNumOpts entries, only those >= kOptLds are used
     uint8_t *out;         // payload output (after the header)
     uint64_t out_cap;
     MF mf;
     EncParams ep;
     PriceLayout pl;
+    uint32_t lane_id;
+#if defined(LZ_PROFILE)
+    uint64_t prof[12], prof_last;
+#endif
 
     // ---- range encoder, range_coder.go:131-138 ----
     uint64_t low, out_n;
@@ -101,11 +163,51 @@ struct Encoder {
     uint32_t longest_len, dist_pairs, add_offset, opt_end, opt_cur, longest_found;
     uint32_t align_price_count, match_price_count, pos_state_mask, lit_pos_mask;
     uint32_t now_pos, finished, state, prev_byte, back_res;
-    // Small runtime-indexed arrays, kept in caller-provided (LDS) memory so that they
-    // never end up in per-lane scratch: kEncSmallWords words.
-    uint32_t *rep_dist, *reps, *rep_lens;  // 4 each
-    uint32_t *len_counter;                 // [2][kPosStatesMax]
-    uint32_t *temp_prices;                 // kNumFullDist, scratch of fill_dist_prices
+    // Small arrays in caller-provided (LDS) memory: never in per-lane scratch.
+    U32P rep_dist, reps, rep_lens, rep_prp;          // 4 each
+    U32P xch;                                        // 16 words exchanged between phases
+    U32P len_counter;                                // [2][kPosStatesMax]
+    U32P temp_prices;                                // kNumFullDist
+    U32P la_tgt, la_price;                           // kLaMax each: target entry (0 = none), price
+    U32P mdist;                                      // current match list, (len, dist) pairs
+
+    LZ_HD void bind_small(U32P small) {
+        rep_dist = small;
+        reps = small + 4;
+        rep_lens = small + 8;
+        rep_prp = small + 12;
+        xch = small + 16;
+        len_counter = small + 64;
+        temp_prices = len_counter + 2 * kPosStatesMax;
+        la_tgt = temp_prices + kNumFullDist;
+        la_price = la_tgt + kLaMax;
+        mdist = la_price + kLaMax;
+    }
+
+    // ------------------------------------------------------- optimum table access
+    LZ_HD uint32_t oprice(uint32_t i) const { return i < kOptLds ? o_price[i] : opt_g[i].price; }
+    LZ_HD uint32_t oback(uint32_t i) const { return i < kOptLds ? o_back[i] : opt_g[i].back; }
+    LZ_HD uint32_t opp(uint32_t i) const { return i < kOptLds ? o_pp[i] : opt_g[i].pp; }
+    LZ_HD uint32_t oback2(uint32_t i) const { return i < kOptLds ? o_back2[i] : opt_g[i].back2; }
+    LZ_HD uint32_t obacks(uint32_t i, uint32_t k) const {
+        return i < kOptLds ? o_backs[4 * i + k] : opt_g[i].backs[k];
+    }
+    LZ_HD void set_price(uint32_t i, uint32_t v) {
+        if (i < kOptLds) o_price[i] = v; else opt_g[i].price = v;
+    }
+    LZ_HD void set_back(uint32_t i, uint32_t v) {
+        if (i < kOptLds) o_back[i] = v; else opt_g[i].back = v;
+    }
+    LZ_HD void set_pp(uint32_t i, uint32_t v) {
+        if (i < kOptLds) o_pp[i] = v; else opt_g[i].pp = v;
+    }
+    LZ_HD void set_back2(uint32_t i, uint32_t v) {
+        if (i < kOptLds) o_back2[i] = v; else opt_g[i].back2 = v;
+    }
+    LZ_HD void set_backs(uint32_t i, uint32_t k, uint32_t v) {
+        if (i < kOptLds) o_backs[4 * i + k] = v; else opt_g[i].backs[k] = v;
+    }
+    LZ_HD uint32_t ostate(uint32_t i) const { return (opp(i) >> 24) & 0xF; }
 
     // ------------------------------------------------------------ range coder
     LZ_HD void rc_put(uint32_t b) {
@@ -129,7 +231,7 @@ struct Encoder {
         low = (uint64_t)(((uint32_t)low) << 8);
     }
     template <class P>
-    LZ_HD void rc_bit(P *pr, uint32_t idx, uint32_t bit) {  // range_coder.go:205-220
+    LZ_HD void rc_bit(P pr, uint32_t idx, uint32_t bit) {  // range_coder.go:205-220
         uint32_t p = pr[idx], bound = (range >> kProbBits) * p;
         if (bit == 0) {
             range = bound;
@@ -155,7 +257,7 @@ struct Encoder {
         }
     }
     template <class P>
-    LZ_HD void bt_encode(P *pr, uint32_t base, uint32_t nbits, uint32_t sym) {
+    LZ_HD void bt_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {
         uint32_t k = 1;
         for (uint32_t i = nbits; i != 0;) {
             i--;
@@ -165,7 +267,7 @@ struct Encoder {
         }
     }
     template <class P>
-    LZ_HD void bt_rev_encode(P *pr, uint32_t base, uint32_t nbits, uint32_t sym) {
+    LZ_HD void bt_rev_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {
         uint32_t k = 1;
         for (uint32_t i = 0; i < nbits; i++) {
             uint32_t b = sym & 1;
@@ -182,7 +284,7 @@ struct Encoder {
     LZ_HD uint32_t price0(uint32_t p) const { return pp[p >> kMoveReducingBits]; }
     LZ_HD uint32_t price1(uint32_t p) const { return pp[(kProbTotal - p) >> kMoveReducingBits]; }
     template <class P>
-    LZ_HD uint32_t bt_price(const P *pr, uint32_t base, uint32_t nbits, uint32_t sym) const {
+    LZ_HD uint32_t bt_price(P pr, uint32_t base, uint32_t nbits, uint32_t sym) const {
         uint32_t res = 0, k = 1;
         for (uint32_t i = nbits; i != 0;) {
             i--;
@@ -193,7 +295,7 @@ struct Encoder {
         return res;
     }
     template <class P>
-    LZ_HD uint32_t bt_rev_price(const P *pr, uint32_t base, uint32_t nbits, uint32_t sym) const {
+    LZ_HD uint32_t bt_rev_price(P pr, uint32_t base, uint32_t nbits, uint32_t sym) const {
         uint32_t res = 0, k = 1;
         for (uint32_t i = nbits; i != 0; i--) {
             uint32_t b = sym & 1;
@@ -208,18 +310,25 @@ struct Encoder {
     // which: 0 = match lengths (P_LEN), 1 = rep lengths (P_REP_LEN)
     LZ_HD uint32_t len_base(uint32_t which) const { return which ? P_REP_LEN : P_LEN; }
     LZ_HD uint32_t len_tab(uint32_t which) const { return which ? pl.rep_len : pl.len; }
-    LZ_HD void len_set_prices(uint32_t which, uint32_t ps) {  // lzma_len_coder.go:66-88,111-114
+    // setPrices / updateTable, lzma_len_coder.go:66-88,111-114: one symbol per lane
+    LZ_HD void len_set_prices(uint32_t which, uint32_t ps) {
         const uint32_t b = len_base(which), nsym = ep.fb + 1 - kMatchMin;
-        uint32_t a0 = price0(probs[b + LEN_CHOICE]), a1 = price1(probs[b + LEN_CHOICE]);
-        uint32_t b0 = a1 + price0(probs[b + LEN_CHOICE + 1]);
-        uint32_t b1 = a1 + price1(probs[b + LEN_CHOICE + 1]);
-        WT *pr = prices + len_tab(which) + ps * kNumLenSyms;
-        uint32_t i = 0;
-        for (; i < kLenLow && i < nsym; i++) pr[i] = (WT)(a0 + bt_price(probs, b + LEN_LOW + (ps << 3), 3, i));
-        for (; i < kLenLow + kLenMid && i < nsym; i++)
-            pr[i] = (WT)(b0 + bt_price(probs, b + LEN_MID + (ps << 3), 3, i - kLenLow));
-        for (; i < nsym; i++)
-            pr[i] = (WT)(b1 + bt_price(probs, b + LEN_HIGH, 8, i - kLenLow - kLenMid));
+        const uint32_t a0 = price0(probs[b + LEN_CHOICE]), a1 = price1(probs[b + LEN_CHOICE]);
+        const uint32_t b0 = a1 + price0(probs[b + LEN_CHOICE + 1]);
+        const uint32_t b1 = a1 + price1(probs[b + LEN_CHOICE + 1]);
+        auto pr = prices + len_tab(which) + ps * kNumLenSyms;
+        LZ_PAR_BEGIN(L)
+        for (uint32_t i = L; i < nsym; i += kLanes) {
+            uint32_t v;
+            if (i < kLenLow)
+                v = a0 + bt_price(probs, b + LEN_LOW + (ps << 3), 3, i);
+            else if (i < kLenLow + kLenMid)
+                v = b0 + bt_price(probs, b + LEN_MID + (ps << 3), 3, i - kLenLow);
+            else
+                v = b1 + bt_price(probs, b + LEN_HIGH, 8, i - kLenLow - kLenMid);
+            pr[i] = (WT)v;
+        }
+        LZ_PAR_END
         len_counter[which * kPosStatesMax + ps] = nsym;
     }
     LZ_HD void len_encode(uint32_t which, uint32_t sym, uint32_t ps) {  // :48-63, :120-126
@@ -270,24 +379,19 @@ struct Encoder {
             ctx = (ctx << 1) | b;
         }
     }
-    LZ_HD uint32_t lit_price(uint32_t sub, bool match_mode, uint32_t mb, uint32_t sym) const {  // :78-102
-        uint32_t price = 0, ctx = 1;
-        int i = 7;
-        if (match_mode) {
-            for (; i >= 0; i--) {
-                uint32_t m = (mb >> i) & 1, b = (sym >> i) & 1;
-                price += price_bit(lit[sub + ((1 + m) << 8) + ctx], b);
-                ctx = (ctx << 1) | b;
-                if (m != b) {
-                    i--;
-                    break;
-                }
-            }
-        }
-        for (; i >= 0; i--) {
-            uint32_t b = (sym >> i) & 1;
-            price += price_bit(lit[sub + ctx], b);
-            ctx = (ctx << 1) | b;
+    // getPrice, :78-102, without the data-dependent loop exit: bit i is priced in the
+    // matched tables while all higher bits of the symbol equal those of the match byte.
+    LZ_HD uint32_t lit_price(uint32_t sub, bool match_mode, uint32_t mb, uint32_t sym) const {
+        uint32_t price = 0;
+        const uint32_t diff = match_mode ? (sym ^ mb) : 0xFFu;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            const uint32_t b = (sym >> i) & 1;
+            const uint32_t ctx = (0x100u | sym) >> (i + 1);        // 1 followed by the higher bits
+            const bool matched = match_mode && (diff >> (i + 1)) == 0;  // higher bits all equal
+            const uint32_t m = (mb >> i) & 1;
+            const uint32_t idx = matched ? ((1 + m) << 8) + ctx : ctx;
+            price += price_bit(lit[sub + idx], b);
         }
         return price;
     }
@@ -295,15 +399,28 @@ struct Encoder {
     // ------------------------------------------------------ window access helpers
     LZ_HD uint32_t avail() const { return n - mfpos; }  // getNumAvailableBytes
     LZ_HD uint32_t index_byte(int32_t index) const { return data[(int64_t)mfpos + index]; }
+    // getMatchLen, lz_window.go:169-182, eight bytes at a time
     LZ_HD uint32_t match_len(int32_t index, uint32_t distance, uint32_t limit) const {
-        int64_t p = (int64_t)mfpos + index;  // lz_window.go:169-182
-        uint32_t left = n - (uint32_t)p;
+        const uint32_t p = (uint32_t)((int64_t)mfpos + index);
+        const uint32_t left = n - p;
         if (limit > left) limit = left;
         const uint8_t *a = data + p;
         const uint8_t *b = a - (int64_t)distance - 1;
         uint32_t r = 0;
-        while (r < limit && a[r] == b[r]) r++;
-        return r;
+        while (r < limit) {
+            if (p + r + 8 <= readable) {
+                const uint64_t x = enc_load8(a + r) ^ enc_load8(b + r);
+                if (x != 0) {
+                    r += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                r += 8;
+            } else {
+                if (a[r] != b[r]) break;
+                r++;
+            }
+        }
+        return r < limit ? r : limit;
     }
 
     LZ_HD uint32_t read_match_distances() {  // lzma_encoder.go:274-285
@@ -356,66 +473,95 @@ struct Encoder {
     }
 
     LZ_HD uint32_t backward(uint32_t cur) {  // :331-357
-        Opt *o = opt;
         opt_end = cur;
-        uint32_t pos_mem = o[cur].pos_prev, back_mem = o[cur].back_prev;
+        uint32_t w = opp(cur);
+        uint32_t pos_mem = w & 0xFFF, back_mem = oback(cur);
         do {
-            if (o[cur].prev1_is_char) {
-                o[pos_mem].back_prev = 0xFFFFFFFFu;
-                o[pos_mem].prev1_is_char = 0;
-                o[pos_mem].pos_prev = (uint16_t)(pos_mem - 1);
-                if (o[cur].prev2) {
-                    o[pos_mem - 1].prev1_is_char = 0;
-                    o[pos_mem - 1].pos_prev = o[cur].pos_prev2;
-                    o[pos_mem - 1].back_prev = o[cur].back_prev2;
+            w = opp(cur);
+            if (w & kPpPrev1) {
+                set_back(pos_mem, 0xFFFFFFFFu);
+                set_pp(pos_mem, (opp(pos_mem) & ~(0xFFFu | kPpPrev1)) | (pos_mem - 1));
+                if (w & kPpPrev2) {
+                    set_pp(pos_mem - 1, (opp(pos_mem - 1) & ~(0xFFFu | kPpPrev1)) | ((w >> 12) & 0xFFF));
+                    set_back(pos_mem - 1, oback2(cur));
                 }
             }
-            uint32_t pp_ = pos_mem, bc = back_mem;
-            back_mem = o[pp_].back_prev;
-            pos_mem = o[pp_].pos_prev;
-            o[pp_].back_prev = bc;
-            o[pp_].pos_prev = (uint16_t)cur;
-            cur = pp_;
+            const uint32_t pprev = pos_mem, bc = back_mem;
+            back_mem = oback(pprev);
+            const uint32_t wp = opp(pprev);
+            pos_mem = wp & 0xFFF;
+            set_back(pprev, bc);
+            set_pp(pprev, (wp & ~0xFFFu) | cur);
+            cur = pprev;
         } while (cur > 0);
-        back_res = o[0].back_prev;
-        opt_cur = o[0].pos_prev;
+        back_res = oback(0);
+        opt_cur = opp(0) & 0xFFF;
         return opt_cur;
     }
-    LZ_HD void extend_end(uint32_t &len_end, uint32_t upto) {
-        while (len_end < upto) opt[++len_end].price = kInfPrice;
-    }
-    LZ_HD void relax(uint32_t idx, uint32_t price, uint32_t pos_prev, uint32_t back_prev) {
-        Opt *t = &opt[idx];
-        if (price < t->price) {
-            t->price = price;
-            t->pos_prev = (uint16_t)pos_prev;
-            t->back_prev = back_prev;
-            t->prev1_is_char = 0;
-        }
-    }
-    LZ_HD void relax2(uint32_t idx, uint32_t price, uint32_t pos_prev, uint32_t prev2,
-                      uint32_t pos_prev2, uint32_t back_prev2) {
-        Opt *t = &opt[idx];
-        if (price < t->price) {
-            t->price = price;
-            t->pos_prev = (uint16_t)pos_prev;
-            t->back_prev = 0;
-            t->prev1_is_char = 1;
-            t->prev2 = (uint8_t)prev2;
-            if (prev2) {
-                t->pos_prev2 = (uint16_t)pos_prev2;
-                t->back_prev2 = back_prev2;
+
+    // The apply phase (see the header comment): entries cur+2 .. new_end.
+    //   old_end:   entries beyond it are new and start at infinity
+    //   rep_lens/rep_prp: plain rep candidates (length < 2 = none)
+    //   start_len/new_len/nmp: plain match candidates over mdist[0..npairs) (new_len 0 = none)
+    //   la_*[0], [1..4], [5+first_la..5+npairs): continuation candidates (la_tgt 0 = none);
+    //   the path words of a continuation follow from the step it continues.
+    LZ_HD void apply(uint32_t cur, uint32_t old_end, uint32_t new_end, uint32_t ps, uint32_t start_len,
+                     uint32_t new_len, uint32_t nmp, uint32_t npairs, uint32_t first_la, bool with_la) {
+        LZ_PAR_BEGIN(L)
+        for (uint32_t x = cur + 2 + L; x <= new_end; x += kLanes) {
+            const uint32_t len = x - cur;
+            uint32_t price = x <= old_end ? oprice(x) : kInfPrice;
+            bool changed = x > old_end;
+            uint32_t back = 0, ppw = 0, back2 = 0;
+            bool is_la = false;
+            if (with_la && la_tgt[0] == x && la_price[0] < price) {
+                price = la_price[0], back = 0, ppw = (cur + 1) | kPpPrev1, back2 = 0, is_la = true, changed = true;
+            }
+            for (uint32_t ri = 0; ri < kNumReps; ri++) {
+                const uint32_t lt = rep_lens[ri];
+                if (lt >= 2 && len <= lt) {
+                    const uint32_t p = rep_prp[ri] + len_price(1, len - kMatchMin, ps);
+                    if (p < price) price = p, back = ri, ppw = cur, is_la = false, changed = true;
+                }
+                if (with_la && la_tgt[1 + ri] == x && la_price[1 + ri] < price) {
+                    price = la_price[1 + ri], back = 0, back2 = ri;
+                    ppw = (cur + lt + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
+                    is_la = true, changed = true;
+                }
+            }
+            if (with_la)
+                for (uint32_t j = first_la; j < npairs; j++)
+                    if (la_tgt[5 + j] == x && la_price[5 + j] < price) {
+                        price = la_price[5 + j], back = 0, back2 = mdist[2 * j + 1] + kNumReps;
+                        ppw = (cur + mdist[2 * j] + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
+                        is_la = true, changed = true;
+                    }
+            if (new_len != 0 && len >= start_len && len <= new_len) {
+                uint32_t j = 0;
+                while (mdist[2 * j] < len) j++;
+                const uint32_t d = mdist[2 * j + 1];
+                const uint32_t p = nmp + pos_len_price(d, len, ps);
+                if (p < price) price = p, back = d + kNumReps, ppw = cur, is_la = false, changed = true;
+            }
+            if (changed) {
+                set_price(x, price);
+                if (price != kInfPrice) {
+                    set_back(x, back);
+                    set_pp(x, ppw);
+                    if (is_la) set_back2(x, back2);
+                }
             }
         }
+        LZ_PAR_END
     }
 
     LZ_HD uint32_t get_optimum(uint32_t position) {  // :359-797
-        Opt *o = opt;
         const uint32_t fb = ep.fb;
         if (opt_end != opt_cur) {
-            uint32_t r = o[opt_cur].pos_prev - opt_cur;
-            back_res = o[opt_cur].back_prev;
-            opt_cur = o[opt_cur].pos_prev;
+            const uint32_t nxt = opp(opt_cur) & 0xFFF;
+            const uint32_t r = nxt - opt_cur;
+            back_res = oback(opt_cur);
+            opt_cur = nxt;
             return r;
         }
         opt_end = opt_cur = 0;
@@ -431,81 +577,77 @@ struct Encoder {
             back_res = 0xFFFFFFFFu;
             return 1;
         }
-        uint32_t rep_max = 0;
-        for (uint32_t i = 0; i < kNumReps; i++) {
-            reps[i] = rep_dist[i];
-            rep_lens[i] = match_len(-1, reps[i], kMatchMax);
-            if (rep_lens[i] > rep_lens[rep_max]) rep_max = i;
+        // rep lengths and the two bytes the literal needs, in parallel
+        LZ_PAR_BEGIN(L)
+        if (L < kNumReps) {
+            reps[L] = rep_dist[L];
+            rep_lens[L] = match_len(-1, rep_dist[L], kMatchMax);
+        } else if (L == 4) {
+            xch[0] = index_byte(-1);
+            xch[1] = index_byte(0 - (int32_t)rep_dist[0] - 1 - 1);
         }
-        if (rep_lens[rep_max] >= fb) {
+        LZ_PAR_END
+        uint32_t rep_max = 0;
+        for (uint32_t i = 1; i < kNumReps; i++)
+            if (rep_lens[i] > rep_lens[rep_max]) rep_max = i;
+        const uint32_t rep_max_len = rep_lens[rep_max];
+        if (rep_max_len >= fb) {
             back_res = rep_max;
-            uint32_t r = rep_lens[rep_max];
-            move_pos(r - 1);
-            return r;
+            move_pos(rep_max_len - 1);
+            return rep_max_len;
         }
         if (len_main >= fb) {
             back_res = mdist[dpairs - 1] + kNumReps;
             move_pos(len_main - 1);
             return len_main;
         }
-        uint32_t cur_byte = index_byte(-1);
-        uint32_t match_byte = index_byte(0 - (int32_t)rep_dist[0] - 1 - 1);
-        if (len_main < 2 && cur_byte != match_byte && rep_lens[rep_max] < 2) {
+        const uint32_t cur_byte0 = xch[0], match_byte0 = xch[1];
+        if (len_main < 2 && cur_byte0 != match_byte0 && rep_max_len < 2) {
             back_res = 0xFFFFFFFFu;
             return 1;
         }
-        o[0].state = (uint8_t)state;
         uint32_t ps = position & pos_state_mask;
-        o[1].price = price0(probs[P_IS_MATCH + LZ_IDX(state, ps)]) +
-                     lit_price(lit_sub(position, prev_byte), !st_is_char(state), match_byte, cur_byte);
-        o[1].back_prev = 0xFFFFFFFFu;
-        o[1].prev1_is_char = 0;
-        uint32_t match_price = price1(probs[P_IS_MATCH + LZ_IDX(state, ps)]);
+        const uint32_t im0 = probs[P_IS_MATCH + LZ_IDX(state, ps)];
+        uint32_t price1_ = price0(im0) + lit_price(lit_sub(position, prev_byte), !st_is_char(state),
+                                                    match_byte0, cur_byte0);
+        uint32_t back1 = 0xFFFFFFFFu;
+        uint32_t match_price = price1(im0);
         uint32_t rep_match_price = match_price + price1(probs[P_IS_REP + state]);
-        if (match_byte == cur_byte) {
-            uint32_t sp = rep_match_price + rep_len1_price(state, ps);
-            if (sp < o[1].price) {
-                o[1].price = sp;
-                o[1].back_prev = 0;
-                o[1].prev1_is_char = 0;
+        if (match_byte0 == cur_byte0) {
+            const uint32_t sp = rep_match_price + rep_len1_price(state, ps);
+            if (sp < price1_) {
+                price1_ = sp;
+                back1 = 0;
             }
         }
-        uint32_t len_end = rep_lens[rep_max];
+        uint32_t len_end = rep_max_len;
         if (len_main > len_end) len_end = len_main;
         if (len_end < 2) {
-            back_res = o[1].back_prev;
+            back_res = back1;
             return 1;
         }
-        o[1].pos_prev = 0;
-        for (int i = 0; i < 4; i++) o[0].backs[i] = reps[i];
-        for (uint32_t l = len_end; l >= 2; l--) o[l].price = kInfPrice;
-        for (uint32_t i = 0; i < kNumReps; i++) {
-            uint32_t rl = rep_lens[i];
-            if (rl < 2) continue;
-            uint32_t price = rep_match_price + pure_rep_price(i, state, ps);
-            do relax(rl, price + len_price(1, rl - 2, ps), 0, i);
-            while (--rl >= 2);
-        }
-        uint32_t normal_match_price = match_price + price0(probs[P_IS_REP + state]);
-        uint32_t len = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2;
-        if (len <= len_main) {
-            uint32_t offs = 0;
-            while (len > mdist[offs]) offs += 2;
-            for (;; len++) {
-                uint32_t d = mdist[offs + 1];
-                relax(len, normal_match_price + pos_len_price(d, len, ps), 0, d + kNumReps);
-                if (len == mdist[offs]) {
-                    offs += 2;
-                    if (offs == dpairs) break;
-                }
-            }
+        set_pp(0, state << 24);
+        for (uint32_t i = 0; i < 4; i++) set_backs(0, i, reps[i]);
+        set_price(1, price1_);
+        set_back(1, back1);
+        set_pp(1, 0);
+        {
+            LZ_PAR_BEGIN(L)
+            if (L < kNumReps) rep_prp[L] = rep_match_price + pure_rep_price(L, state, ps);
+            LZ_PAR_END
+            const uint32_t nmp = match_price + price0(probs[P_IS_REP + state]);
+            const uint32_t start_len = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2;
+            const uint32_t new_len = start_len <= len_main ? mdist[dpairs - 2] : 0;
+            apply(0, 1, len_end, ps, start_len, new_len, nmp, dpairs >> 1, 0, false);
         }
 
         uint32_t cur = 0;
         for (;;) {
             cur++;
             if (cur == len_end) return backward(cur);
+            LZ_LAP(5)
             uint32_t new_len = read_match_distances();
+            LZ_LAP(0)
             dpairs = dist_pairs;
             if (new_len >= fb) {
                 longest_len = new_len;
@@ -513,197 +655,291 @@ struct Encoder {
                 return backward(cur);
             }
             position++;
-            uint32_t pos_prev = o[cur].pos_prev, st;
-            const uint32_t c_p1 = o[cur].prev1_is_char, c_p2 = o[cur].prev2;
-            const uint32_t c_bp = o[cur].back_prev;
+            // ---- state and reps of the path that reaches cur (:525-597)
+            const uint32_t cw = opp(cur);
+            uint32_t pos_prev = cw & 0xFFF, st;
+            const bool c_p1 = (cw & kPpPrev1) != 0, c_p2 = (cw & kPpPrev2) != 0;
+            const uint32_t c_bp = oback(cur);
             if (c_p1) {
                 pos_prev--;
                 if (c_p2) {
-                    st = o[o[cur].pos_prev2].state;
-                    st = o[cur].back_prev2 < kNumReps ? st_rep(st) : st_match(st);
+                    st = ostate((cw >> 12) & 0xFFF);
+                    st = oback2(cur) < kNumReps ? st_rep(st) : st_match(st);
                 } else
-                    st = o[pos_prev].state;
+                    st = ostate(pos_prev);
                 st = st_char(st);
             } else
-                st = o[pos_prev].state;
+                st = ostate(pos_prev);
             if (pos_prev == cur - 1) {
                 st = c_bp == 0 ? st_shortrep(st) : st_char(st);
             } else {
                 uint32_t pos;
                 if (c_p1 && c_p2) {
-                    pos_prev = o[cur].pos_prev2;
-                    pos = o[cur].back_prev2;
+                    pos_prev = (cw >> 12) & 0xFFF;
+                    pos = oback2(cur);
                     st = st_rep(st);
                 } else {
                     pos = c_bp;
                     st = pos < kNumReps ? st_rep(st) : st_match(st);
                 }
-                const uint32_t q0 = o[pos_prev].backs[0], q1 = o[pos_prev].backs[1],
-                               q2 = o[pos_prev].backs[2], q3 = o[pos_prev].backs[3];
+                const uint32_t q0 = obacks(pos_prev, 0), q1 = obacks(pos_prev, 1),
+                               q2 = obacks(pos_prev, 2), q3 = obacks(pos_prev, 3);
+                uint32_t r0, r1, r2, r3;
                 if (pos < kNumReps) {
                     if (pos == 0) {
-                        reps[0] = q0, reps[1] = q1, reps[2] = q2, reps[3] = q3;
+                        r0 = q0, r1 = q1, r2 = q2, r3 = q3;
                     } else if (pos == 1) {
-                        reps[0] = q1, reps[1] = q0, reps[2] = q2, reps[3] = q3;
+                        r0 = q1, r1 = q0, r2 = q2, r3 = q3;
                     } else if (pos == 2) {
-                        reps[0] = q2, reps[1] = q0, reps[2] = q1, reps[3] = q3;
+                        r0 = q2, r1 = q0, r2 = q1, r3 = q3;
                     } else {
-                        reps[0] = q3, reps[1] = q0, reps[2] = q1, reps[3] = q2;
+                        r0 = q3, r1 = q0, r2 = q1, r3 = q2;
                     }
                 } else {
-                    reps[0] = pos - kNumReps, reps[1] = q0, reps[2] = q1, reps[3] = q2;
+                    r0 = pos - kNumReps, r1 = q0, r2 = q1, r3 = q2;
                 }
+                reps[0] = r0, reps[1] = r1, reps[2] = r2, reps[3] = r3;
             }
-            o[cur].state = (uint8_t)st;
-            for (int i = 0; i < 4; i++) o[cur].backs[i] = reps[i];
-            const uint32_t cur_price = o[cur].price;
-            cur_byte = index_byte(-1);
-            match_byte = index_byte(0 - (int32_t)reps[0] - 1 - 1);
+            set_pp(cur, (cw & ~(0xFu << 24)) | (st << 24));
+            for (uint32_t i = 0; i < 4; i++) set_backs(cur, i, reps[i]);
+            const uint32_t cur_price = oprice(cur);
             ps = position & pos_state_mask;
             const uint32_t is_match_p = probs[P_IS_MATCH + LZ_IDX(st, ps)];
-            const uint32_t cur_and1 = cur_price + price0(is_match_p) +
-                                      lit_price(lit_sub(position, index_byte(-2)), !st_is_char(st),
-                                                match_byte, cur_byte);
-            Opt *nx = &o[cur + 1];
-            bool next_is_char = false;
-            if (cur_and1 < nx->price) {
-                nx->price = cur_and1;
-                nx->pos_prev = (uint16_t)cur;
-                nx->back_prev = 0xFFFFFFFFu;
-                nx->prev1_is_char = 0;
-                next_is_char = true;
-            }
             match_price = cur_price + price1(is_match_p);
             rep_match_price = match_price + price1(probs[P_IS_REP + st]);
-            if (match_byte == cur_byte && !(nx->pos_prev < cur && nx->back_prev == 0)) {
-                uint32_t sp = rep_match_price + rep_len1_price(st, ps);
-                if (sp <= nx->price) {
-                    nx->price = sp;
-                    nx->pos_prev = (uint16_t)cur;
-                    nx->back_prev = 0;
-                    nx->prev1_is_char = 0;
-                    next_is_char = true;
-                }
-            }
+            const uint32_t nmp = match_price + price0(probs[P_IS_REP + st]);
             uint32_t avail_full = kNumOpts - 1 - cur;
             if (avail() + 1 < avail_full) avail_full = avail() + 1;
-            uint32_t av = avail_full;
-            if (av < 2) continue;
-            if (av > fb) av = fb;
-            if (!next_is_char && match_byte != cur_byte) {
-                uint32_t t = avail_full - 1 < fb ? avail_full - 1 : fb;
-                uint32_t l2 = match_len(0, reps[0], t);
-                if (l2 >= 2) {
-                    uint32_t s2 = st_char(st);
-                    uint32_t psn = (position + 1) & pos_state_mask;
-                    uint32_t nrmp = cur_and1 + price1(probs[P_IS_MATCH + LZ_IDX(s2, psn)]) +
-                                    price1(probs[P_IS_REP + s2]);
-                    uint32_t offset = cur + 1 + l2;
-                    extend_end(len_end, offset);
-                    relax2(offset, nrmp + rep_price(0, l2, s2, psn), cur + 1, 0, 0, 0);
-                }
-            }
-            uint32_t start_len = 2;
-            for (uint32_t ri = 0; ri < kNumReps; ri++) {
-                uint32_t lt = match_len(-1, reps[ri], av);
-                if (lt < 2) continue;
-                const uint32_t lt_keep = lt;
-                extend_end(len_end, cur + lt);
-                const uint32_t prp = rep_match_price + pure_rep_price(ri, st, ps);
-                do relax(cur + lt, prp + len_price(1, lt - kMatchMin, ps), cur, ri);
-                while (--lt >= 2);
-                lt = lt_keep;
-                if (ri == 0) start_len = lt + 1;
-                if (lt < avail_full) {
-                    uint32_t t = avail_full - 1 - lt < fb ? avail_full - 1 - lt : fb;
-                    uint32_t l2 = match_len((int32_t)lt, reps[ri], t);
-                    if (l2 >= 2) {
-                        uint32_t s2 = st_rep(st);
-                        uint32_t psn = (position + lt) & pos_state_mask;
-                        uint32_t calcp = prp + len_price(1, lt - kMatchMin, ps) +
-                                         price0(probs[P_IS_MATCH + LZ_IDX(s2, psn)]) +
-                                         lit_price(lit_sub(position + lt, index_byte((int32_t)lt - 2)), true,
-                                                   index_byte((int32_t)lt - 1 - (int32_t)(reps[ri] + 1)),
-                                                   index_byte((int32_t)lt - 1));
-                        s2 = st_char(s2);
-                        psn = (position + lt + 1) & pos_state_mask;
-                        uint32_t nmp = calcp + price1(probs[P_IS_MATCH + LZ_IDX(s2, psn)]);
-                        uint32_t nrmp = nmp + price1(probs[P_IS_REP + s2]);
-                        uint32_t offset = lt + 1 + l2;
-                        extend_end(len_end, cur + offset);
-                        relax2(cur + offset, nrmp + rep_price(0, l2, s2, psn), cur + lt + 1, 1, cur, ri);
-                    }
-                }
-            }
-            if (new_len > av) {
+            const uint32_t av = avail_full < fb ? avail_full : fb;
+            const bool do_rest = avail_full >= 2;
+            uint32_t npairs = dpairs >> 1;
+            if (do_rest && new_len > av) {  // :724-731
                 new_len = av;
-                for (dpairs = 0; new_len > mdist[dpairs]; dpairs += 2) {
-                }
-                mdist[dpairs] = new_len;
-                dpairs += 2;
+                uint32_t j = 0;
+                while (new_len > mdist[2 * j]) j++;
+                mdist[2 * j] = new_len;
+                npairs = j + 1;
             }
-            if (new_len >= start_len) {
-                normal_match_price = match_price + price0(probs[P_IS_REP + st]);
-                extend_end(len_end, cur + new_len);
-                uint32_t offs = 0;
-                while (start_len > mdist[offs]) offs += 2;
-                for (uint32_t lt = start_len;; lt++) {
-                    const uint32_t cb = mdist[offs + 1];
-                    uint32_t cp = normal_match_price + pos_len_price(cb, lt, ps);
-                    relax(cur + lt, cp, cur, cb + kNumReps);
-                    if (lt == mdist[offs]) {
-                        if (lt < avail_full) {
-                            uint32_t t = avail_full - 1 - lt < fb ? avail_full - 1 - lt : fb;
-                            uint32_t l2 = match_len((int32_t)lt, cb, t);
-                            if (l2 >= 2) {
-                                uint32_t s2 = st_match(st);
-                                uint32_t psn = (position + lt) & pos_state_mask;
-                                uint32_t calcp =
-                                    cp + price0(probs[P_IS_MATCH + LZ_IDX(s2, psn)]) +
-                                    lit_price(lit_sub(position + lt, index_byte((int32_t)lt - 2)), true,
-                                              index_byte((int32_t)lt - ((int32_t)cb + 1) - 1),
-                                              index_byte((int32_t)lt - 1));
-                                s2 = st_char(s2);
-                                psn = (position + lt + 1) & pos_state_mask;
-                                uint32_t nmp = calcp + price1(probs[P_IS_MATCH + LZ_IDX(s2, psn)]);
-                                uint32_t nrmp = nmp + price1(probs[P_IS_REP + s2]);
-                                uint32_t offset = lt + 1 + l2;
-                                extend_end(len_end, cur + offset);
-                                relax2(cur + offset, nrmp + rep_price(0, l2, s2, psn), cur + lt + 1, 1,
-                                       cur, cb + kNumReps);
+
+            LZ_LAP(1)
+            // ---- the round: every lane runs the same code on its own task.
+            //   lanes 0-3: rep match L (:661-663) and its continuation (:689-721)
+            //   lane 4:    the literal (:599-603) and rep0 after it (:635-638)
+            //   lanes 8..: continuation of pair L-8 of the match list (:753-787)
+            // A task is two byte streams a (here) and b (dist+1 back): s1 equal bytes, then a
+            // literal, then s2 equal bytes.  Sixteen bytes of both are fetched up front, which
+            // covers nearly every task in one memory round trip.
+            LZ_PAR_BEGIN(L)
+            for (uint32_t jbase = 0; jbase == 0 || jbase < npairs; jbase += kLanes - 8) {
+                const bool first = jbase == 0;
+                const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
+                const bool is_rep = first && L < kNumReps, is_lit = first && L == 4;
+                const bool is_pair = do_rest && L >= 8 && j < npairs;
+                uint32_t a_off = mfpos - 1, dist = 0, lim1 = 0, lim2 = 0, lt_pair = 0;
+                if (is_rep) {
+                    dist = reps[L];
+                    if (do_rest) lim1 = av;
+                } else if (is_lit) {
+                    dist = reps[0];
+                    if (do_rest) lim2 = avail_full - 1 < fb ? avail_full - 1 : fb;
+                } else if (is_pair) {
+                    lt_pair = mdist[2 * j], dist = mdist[2 * j + 1];
+                    a_off += lt_pair;
+                    if (lt_pair < avail_full) lim2 = avail_full - 1 - lt_pair < fb ? avail_full - 1 - lt_pair : fb;
+                }
+                const bool active = is_rep || is_lit || (is_pair && lim2 != 0);
+                uint32_t s1 = 0, s2 = 0, cur_b = 0, match_b = 0, prev_b = 0;
+                bool tail = false;
+                if (active) {
+                    const uint8_t *a = data + a_off;
+                    const uint8_t *b = a - (int64_t)dist - 1;
+                    const uint32_t left = n - a_off;  // bytes of the chunk from a on (>= 1)
+                    if (a_off + 16 <= readable) {
+                        const uint64_t x0 = enc_load8(a) ^ enc_load8(b), x1 = enc_load8(a + 8) ^ enc_load8(b + 8);
+                        const uint32_t pv = a[-1];
+                        // equal bytes from offset `from` inside the 16 fetched (16 - from if all equal)
+                        auto run16 = [&](uint32_t from) -> uint32_t {
+                            if (from >= 16) return 0;
+                            uint64_t lo = x0, hi = x1;
+                            if (from >= 8) {
+                                lo = hi >> (8 * (from - 8));
+                                return lo ? (uint32_t)__builtin_ctzll(lo) >> 3 : 16 - from;
+                            }
+                            lo >>= 8 * from;
+                            if (lo) return (uint32_t)__builtin_ctzll(lo) >> 3;
+                            return (8 - from) + (hi ? (uint32_t)__builtin_ctzll(hi) >> 3 : 8);
+                        };
+                        if (lim1) {
+                            uint32_t lim = lim1 < left ? lim1 : left;
+                            s1 = run16(0);
+                            if (s1 == 16 && lim > 16) s1 = 16 + match_len((int32_t)(a_off + 16 - mfpos), dist, lim - 16);
+                            if (s1 > lim) s1 = lim;
+                        }
+                        tail = is_rep ? (s1 >= 2 && s1 < avail_full) : true;
+                        if (tail) {
+                            if (is_rep) lim2 = avail_full - 1 - s1 < fb ? avail_full - 1 - s1 : fb;
+                            if (s1 < 16) {
+                                const uint32_t sh = 8 * (s1 & 7);
+                                cur_b = (uint32_t)((s1 < 8 ? enc_load8(a) : enc_load8(a + 8)) >> sh) & 0xFF;
+                                match_b = (uint32_t)((s1 < 8 ? enc_load8(b) : enc_load8(b + 8)) >> sh) & 0xFF;
+                            } else {
+                                cur_b = a[s1], match_b = b[s1];
+                            }
+                            prev_b = s1 ? a[s1 - 1] : pv;
+                            if (lim2) {
+                                const uint32_t from = s1 + 1;
+                                uint32_t lim = left > from ? left - from : 0;
+                                if (lim2 < lim) lim = lim2;
+                                s2 = run16(from);
+                                if (from + s2 >= 16 && lim > s2)
+                                    s2 += match_len((int32_t)(a_off + from + s2 - mfpos), dist, lim - s2);
+                                if (s2 > lim) s2 = lim;
                             }
                         }
-                        offs += 2;
-                        if (offs == dpairs) break;
+                    } else {  // last bytes of the buffer: byte-wise
+                        const int32_t ia = (int32_t)(a_off - mfpos);
+                        if (lim1) s1 = match_len(ia, dist, lim1);
+                        tail = is_rep ? (s1 >= 2 && s1 < avail_full) : true;
+                        if (tail) {
+                            if (is_rep) lim2 = avail_full - 1 - s1 < fb ? avail_full - 1 - s1 : fb;
+                            cur_b = a[s1], match_b = b[s1], prev_b = a[(int32_t)s1 - 1];
+                            if (lim2) s2 = match_len(ia + (int32_t)s1 + 1, dist, lim2);
+                        }
+                    }
+                }
+                uint32_t rprp = 0;
+                if (is_rep) rprp = rep_match_price + pure_rep_price(L, st, ps);
+                uint32_t tgt = 0;
+                if (tail && (is_lit || s2 >= 2)) {
+                    const uint32_t lt = is_rep ? s1 : lt_pair;  // 0 for the literal lane
+                    const uint32_t pos_after = position + lt;
+                    const bool mode = is_lit ? !st_is_char(st) : true;
+                    const uint32_t litp = lit_price(lit_sub(pos_after, prev_b), mode, match_b, cur_b);
+                    if (is_lit) {
+                        xch[0] = cur_b, xch[1] = match_b, xch[2] = litp, xch[3] = s2;
+                    } else {
+                        const uint32_t s_after = is_rep ? st_rep(st) : st_match(st);
+                        const uint32_t base = is_rep ? rprp + len_price(1, lt - kMatchMin, ps)
+                                                     : nmp + pos_len_price(dist, lt, ps);
+                        uint32_t psn = pos_after & pos_state_mask;
+                        uint32_t p = base + price0(probs[P_IS_MATCH + LZ_IDX(s_after, psn)]) + litp;
+                        const uint32_t s2s = st_char(s_after);
+                        psn = (pos_after + 1) & pos_state_mask;
+                        p += price1(probs[P_IS_MATCH + LZ_IDX(s2s, psn)]) + price1(probs[P_IS_REP + s2s]);
+                        p += rep_price(0, s2, s2s, psn);
+                        tgt = cur + lt + 1 + s2;
+                        la_price[is_rep ? 1 + L : 5 + j] = p;
+                    }
+                }
+                if (is_rep) {
+                    rep_lens[L] = s1, rep_prp[L] = rprp, la_tgt[1 + L] = tgt;
+                } else if (is_lit) {
+                    la_tgt[0] = 0;
+                } else if (do_rest && L >= 8 && j < npairs) {
+                    la_tgt[5 + j] = tgt;
+                }
+            }
+            LZ_PAR_END
+
+            LZ_LAP(2)
+            // ---- literal and short rep into entry cur+1 (:598-624)
+            const uint32_t cur_byte = xch[0], match_byte = xch[1];
+            const uint32_t cur_and1 = cur_price + price0(is_match_p) + xch[2];
+            uint32_t nx_price = oprice(cur + 1);
+            bool next_is_char = false, nx_changed = false;
+            uint32_t nx_back = 0, nx_pp = 0;
+            if (cur_and1 < nx_price) {
+                nx_price = cur_and1, nx_back = 0xFFFFFFFFu, nx_pp = cur;
+                next_is_char = true, nx_changed = true;
+            }
+            if (match_byte == cur_byte) {
+                bool blocked;
+                if (nx_changed)
+                    blocked = false;  // posPrev == cur is not < cur
+                else
+                    blocked = (opp(cur + 1) & 0xFFF) < cur && oback(cur + 1) == 0;
+                if (!blocked) {
+                    const uint32_t sp = rep_match_price + rep_len1_price(st, ps);
+                    if (sp <= nx_price) {
+                        nx_price = sp, nx_back = 0, nx_pp = cur;
+                        next_is_char = true, nx_changed = true;
                     }
                 }
             }
+            if (nx_changed) {
+                set_price(cur + 1, nx_price);
+                set_back(cur + 1, nx_back);
+                set_pp(cur + 1, nx_pp);
+            }
+            if (!do_rest) continue;
+
+            // ---- continuation of the literal (:635-658)
+            uint32_t new_end = len_end;
+            if (!next_is_char && match_byte != cur_byte) {
+                const uint32_t l2 = xch[3];
+                if (l2 >= 2) {
+                    const uint32_t s2 = st_char(st);
+                    const uint32_t psn = (position + 1) & pos_state_mask;
+                    const uint32_t nrmp = cur_and1 + price1(probs[P_IS_MATCH + LZ_IDX(s2, psn)]) +
+                                          price1(probs[P_IS_REP + s2]);
+                    la_tgt[0] = cur + 1 + l2;
+                    la_price[0] = nrmp + rep_price(0, l2, s2, psn);
+                    if (cur + 1 + l2 > new_end) new_end = cur + 1 + l2;
+                }
+            }
+
+            const uint32_t start_len = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2;
+            for (uint32_t ri = 0; ri < kNumReps; ri++) {
+                const uint32_t lt = rep_lens[ri];
+                if (lt >= 2 && cur + lt > new_end) new_end = cur + lt;
+                const uint32_t tg = la_tgt[1 + ri];
+                if (tg > new_end) new_end = tg;
+            }
+            uint32_t first_la = npairs, plain_len = 0;
+            if (new_len >= start_len) {
+                plain_len = new_len;
+                if (cur + new_len > new_end) new_end = cur + new_len;
+                first_la = 0;
+                while (mdist[2 * first_la] < start_len) first_la++;
+                for (uint32_t j = first_la; j < npairs; j++) {
+                    const uint32_t tg = la_tgt[5 + j];
+                    if (tg > new_end) new_end = tg;
+                }
+            }
+            LZ_LAP(3)
+            apply(cur, len_end, new_end, ps, start_len, plain_len, nmp, npairs, first_la, true);
+            LZ_LAP(4)
+            len_end = new_end;
         }
     }
 
     LZ_HD void fill_dist_prices() {  // :801-827
-        uint32_t *temp = temp_prices;
-        for (uint32_t i = kStartPosModel; i < kNumFullDist; i++) {
+        auto temp = temp_prices;
+        LZ_PAR_BEGIN(L)
+        for (uint32_t i = kStartPosModel + L; i < kNumFullDist; i += kLanes) {
             uint32_t slot = pos_slot(i), fbits = (slot >> 1) - 1, base = (2 | (slot & 1)) << fbits;
             temp[i] = bt_rev_price(probs, P_POS_SPEC + base - slot - 1, fbits, i - base);
         }
-        for (uint32_t lps = 0; lps < kNumLenToPos; lps++) {
-            WT *sp = prices + pl.pos_slot + (lps << kPosSlotBits);
-            uint32_t slot;
-            for (slot = 0; slot < ep.dist_table_size; slot++)
-                sp[slot] = (WT)bt_price(probs, P_POS_SLOT + (lps << kPosSlotBits), kPosSlotBits, slot);
-            for (slot = kEndPosModel; slot < ep.dist_table_size; slot++)
-                sp[slot] = (WT)(sp[slot] + ((((slot >> 1) - 1) - kAlignBits) << kPriceShift));
-            WT *dp = prices + pl.dist + lps * kNumFullDist;
-            uint32_t i;
-            for (i = 0; i < kStartPosModel; i++) dp[i] = sp[i];
-            for (; i < kNumFullDist; i++) dp[i] = (WT)(sp[pos_slot(i)] + temp[i]);
+        for (uint32_t k = L; k < kNumLenToPos * ep.dist_table_size; k += kLanes) {
+            const uint32_t lps = k / ep.dist_table_size, slot = k % ep.dist_table_size;
+            uint32_t v = bt_price(probs, P_POS_SLOT + (lps << kPosSlotBits), kPosSlotBits, slot);
+            if (slot >= kEndPosModel) v += (((slot >> 1) - 1) - kAlignBits) << kPriceShift;
+            prices[pl.pos_slot + (lps << kPosSlotBits) + slot] = (WT)v;
         }
+        LZ_PAR_END
+        LZ_PAR_BEGIN(L)
+        for (uint32_t k = L; k < kNumLenToPos * kNumFullDist; k += kLanes) {
+            const uint32_t lps = k / kNumFullDist, i = k % kNumFullDist;
+            auto sp = prices + pl.pos_slot + (lps << kPosSlotBits);
+            prices[pl.dist + k] = (WT)(i < kStartPosModel ? sp[i] : sp[pos_slot(i)] + temp[i]);
+        }
+        LZ_PAR_END
         match_price_count = 0;
     }
     LZ_HD void fill_align_prices() {  // :829-834
-        for (uint32_t i = 0; i < kAlignSize; i++)
-            prices[pl.align + i] = (WT)bt_rev_price(probs, P_ALIGN, kAlignBits, i);
+        LZ_PAR_BEGIN(L)
+        if (L < kAlignSize) prices[pl.align + L] = (WT)bt_rev_price(probs, P_ALIGN, kAlignBits, L);
+        LZ_PAR_END
         align_price_count = 0;
     }
 
@@ -745,7 +981,9 @@ struct Encoder {
             return;
         }
         for (;;) {
+            LZ_LAP(7)
             uint32_t len = get_optimum(now_pos);
+            LZ_LAP(6)
             uint32_t pos = back_res;
             uint32_t ps = now_pos & pos_state_mask;
             uint32_t cs = LZ_IDX(state, ps);
@@ -831,13 +1069,9 @@ struct Encoder {
 #undef LZ_IDX
 
     // Models must already hold kProbInit and pp must be built.  Encodes the whole
-    // chunk; returns the payload size (header excluded) or sets overflow.
-    LZ_HD void run(uint32_t *small) {
-        rep_dist = small;
-        reps = small + 4;
-        rep_lens = small + 8;
-        len_counter = small + 12;
-        temp_prices = small + 12 + 2 * kPosStatesMax;
+    // chunk; out_n receives the payload size (header excluded).
+    LZ_HD void run(U32P small) {
+        bind_small(small);
         low = 0;
         out_n = 0;
         cache_size = 1;

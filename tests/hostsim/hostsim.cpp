@@ -99,22 +99,28 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     lz::EncParams ep = {fb, lc, lp, pb, 1u << dict_log, dict_log * 2, (uint32_t)(eos != 0)};
     std::vector<lz::prob_t> probs(lz::kNumBaseProbs + ((size_t)0x300 << (lc + lp)), lz::kProbInit);
     std::vector<uint16_t> prices(lz::price_layout(pb).total, 0), pp(512);
-    std::vector<lz::Opt> opt(lz::kNumOpts);
-    std::vector<uint32_t> mdist(2 * (lz::kMatchMax + 1) + 2), small(lz::kEncSmallWords);
+    std::vector<lz::OptG> opt_g(lz::kNumOpts);
+    std::vector<uint32_t> opt_l(8 * lz::kOptLds), small(lz::kEncSmallWords);
     lz::build_prob_prices(pp.data(), 0, 1);
-    lz::Encoder<ChainMFRef, lz::prob_t, lz::prob_t, uint16_t> e;
+    lz::Encoder<ChainMFRef, lz::prob_t *> e;
     e.data = padded.data();
     e.n = (uint32_t)n;
+    e.readable = (uint32_t)n;  // exercises the byte-wise tail of match_len
     e.probs = probs.data();
     e.lit = probs.data() + lz::P_LIT;
     e.prices = prices.data();
     e.pp = pp.data();
-    e.opt = opt.data();
-    e.mdist = mdist.data();
+    e.o_price = opt_l.data();
+    e.o_back = e.o_price + lz::kOptLds;
+    e.o_pp = e.o_back + lz::kOptLds;
+    e.o_back2 = e.o_pp + lz::kOptLds;
+    e.o_backs = e.o_back2 + lz::kOptLds;
+    e.opt_g = opt_g.data();
     e.out = out + lz::kHeaderSize;
     e.out_cap = out_cap - lz::kHeaderSize;
     e.mf = ChainMFRef{&cm};
     e.ep = ep;
+    e.lane_id = 0;
     lz::write_header(out, ep, eos ? -1 : (int64_t)n);
     e.run(small.data());
     *out_n = lz::kHeaderSize + e.out_n;

@@ -1,0 +1,24 @@
+"""One encode call on synthetic Markov text, for rocprofv3 runs."""
+import ctypes as C
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from lzma_amd import _native as N, codec
+from tests import synth
+nchunks = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
+L = N.lib()
+dev = torch.device("cuda:0")
+n = nchunks * chunk
+d_in = torch.from_numpy(synth.markov(n)).to(dev)
+in_off = torch.arange(0, n + 1, chunk, dtype=torch.int64, device=dev)
+cap = L.lzma_amd_encode_bound(chunk)
+out_off = torch.arange(0, (nchunks + 1) * cap, cap, dtype=torch.int64, device=dev)
+d_out = torch.empty(nchunks * cap, dtype=torch.uint8, device=dev)
+sizes = torch.zeros(nchunks, dtype=torch.int64, device=dev)
+status = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+p = codec.make_params(22, 128)
+N.check(L.lzma_amd_encode_chunks_dev(d_in.data_ptr(), in_off.data_ptr(), nchunks, n, C.byref(p), d_out.data_ptr(),
+                                     out_off.data_ptr(), sizes.data_ptr(), status.data_ptr(), None))
+print("positions", n, N.last_timing(), "ratio", sizes.sum().item() / n, flush=True)
