@@ -29,6 +29,9 @@ namespace {
 // list (one per lane) and the result word of the position after it are requested
 // one call ahead and are usually there when needed.
 struct MfFunctor {
+    static __device__ uint64_t uni64(uint64_t v) {
+        return ((uint64_t)lz::U((uint32_t)(v >> 32)) << 32) | lz::U((uint32_t)v);
+    }
     const uint64_t *meta;
     const uint32_t *arena;
     uint32_t job_start, lane, n_total;
@@ -37,7 +40,7 @@ struct MfFunctor {
     uint32_t pf_word;
     __device__ uint32_t operator()(uint32_t pos, LZ_LDS uint32_t *out) {
         const bool hit = pos == pf_pos;
-        const uint64_t m = hit ? pf_meta : meta[job_start + pos];
+        const uint64_t m = uni64(hit ? pf_meta : meta[job_start + pos]);
         const uint32_t c = lz::mf_meta_count(m);
         if (hit && 2 * c <= 64) {
             if (lane < 2 * c) out[lane] = pf_word;
@@ -48,7 +51,7 @@ struct MfFunctor {
         uint32_t g1 = job_start + pos + 1, g2 = job_start + pos + 2;
         if (g1 >= n_total) g1 = n_total - 1;
         if (g2 >= n_total) g2 = n_total - 1;
-        const uint64_t m1 = hit ? pf_meta2 : meta[g1];
+        const uint64_t m1 = uni64(hit ? pf_meta2 : meta[g1]);
         const uint32_t c1 = lz::mf_meta_count(m1);
         uint32_t w = 0;
         if (2 * c1 <= 64 && lane < 2 * c1) w = arena[2 * lz::mf_meta_off(m1) + lane];
@@ -70,7 +73,7 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t pb) {
     l.prices = (l.probs + nprobs * 2 + 15) & ~15u;
     l.pp = (l.prices + lz::price_layout(pb).total * 2 + 15) & ~15u;
     l.opt = l.pp + 512 * 2;
-    l.small = l.opt + 8 * lz::kOptLds * 4;
+    l.small = l.opt + (lz::kRecWin + lz::kBksWin) * 16;
     l.total = l.small + lz::kEncSmallWords * 4;
     return l;
 }
@@ -124,11 +127,8 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         e.lit = lit;
         e.prices = prices;
         e.pp = pp;
-        e.o_price = optl;
-        e.o_back = optl + lz::kOptLds;
-        e.o_pp = optl + 2 * lz::kOptLds;
-        e.o_back2 = optl + 3 * lz::kOptLds;
-        e.o_backs = optl + 4 * lz::kOptLds;
+        e.o_rec = (LZ_LDS lz::Rec *)optl;
+        e.o_bks = (LZ_LDS lz::Reps *)(optl + 4 * lz::kRecWin);
         e.opt_g = opt_scratch + (uint64_t)blockIdx.x * lz::kNumOpts;
         e.lane_id = lane;
         e.out = out + ob + lz::kHeaderSize;

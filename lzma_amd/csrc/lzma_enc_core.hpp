@@ -25,9 +25,10 @@
 //                fixed order -- continuation of literal, then per rep its lengths and
 //                its continuation, then match continuations by pair, then the plain
 //                match length -- so applying them per entry gives the same table.)
-//   * models, price tables (16-bit) and the first kOptLds entries of the optimum
-//     table live in LDS (structure-of-arrays, so the apply phase is bank-conflict
-//     free); the rest of the 4096 entries sits in HBM and is almost never touched;
+//   * the non-literal models, the 16-bit price tables and a ring window of the
+//     optimum table that follows `cur` live in LDS; the full 4096-entry table sits
+//     in HBM (written through), because on text the parse runs to the end of it
+//     almost every time;
 //   * match lengths are measured eight bytes at a time;
 //   * getPosSlot is computed with a count-leading-zeros instead of a 2 KiB table.
 //
@@ -41,10 +42,15 @@
 namespace lz {
 
 constexpr uint32_t kLanes = 64;
-#ifndef LZ_OPT_LDS
-#define LZ_OPT_LDS 128
+// The optimum table (4096 entries) lives in HBM; LDS holds a ring window of it that
+// follows the parse position `cur`: entries [cur - kRecBack, cur - kRecBack + kRecWin)
+// of the path records and [cur - kBksWin + 1, cur] of the rep-distance records.
+#ifndef LZ_REC_WIN
+#define LZ_REC_WIN 256
 #endif
-constexpr uint32_t kOptLds = LZ_OPT_LDS;     // optimum-table entries kept in LDS
+constexpr uint32_t kRecWin = LZ_REC_WIN;           // power of two
+constexpr uint32_t kRecBack = (kRecWin * 3) / 8;   // entries kept behind cur
+constexpr uint32_t kBksWin = kRecWin / 2;          // power of two
 constexpr uint32_t kLaMax = 5 + kMatchMax + 1;  // continuation records: literal, 4 reps, pairs
 constexpr uint32_t kMdistWords = 2 * (kMatchMax + 1) + 2;
 // uint32 words of caller-provided scratch besides the tables (see Encoder::bind_small)
@@ -81,8 +87,15 @@ struct EncParams {
 // Optimum-table entry beyond the LDS window (`optimal`, lzma_encoder.go:167-181).
 // pp packs posPrev (bits 0-11), posPrev2 (12-23), state (24-27), prev1IsChar (28),
 // prev2 (29).
+struct __attribute__((aligned(16))) Rec {
+    uint32_t price, back, pp, back2;
+};
+struct __attribute__((aligned(16))) Reps {
+    uint32_t r[4];
+};
 struct OptG {
-    uint32_t price, back, pp, back2, backs[4];
+    Rec rec;
+    Reps bks;
 };
 constexpr uint32_t kPpPrev1 = 1u << 28, kPpPrev2 = 1u << 29;
 
@@ -123,6 +136,14 @@ LZ_HD PriceLayout price_layout(uint32_t pb) {
     return l;
 }
 
+// U(v): v is known to be the same on every lane; on the GPU this moves it to a scalar
+// register so that the code depending on it runs on the scalar unit with real branches.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+LZ_D uint32_t U(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#else
+LZ_HD uint32_t U(uint32_t v) { return v; }
+#endif
+
 LZ_HD uint64_t enc_load8(const uint8_t *p) {
     uint64_t v;
     __builtin_memcpy(&v, p, 8);
@@ -142,8 +163,10 @@ struct Encoder {
     LP lit;               // 0x300 << (lc+lp) literal models (LDS or HBM)
     LZ_LDS WT *prices;    // price_layout(pb).total entries
     const LZ_LDS WT *pp;  // 512-entry bit-price table
-    U32P o_price, o_back, o_pp, o_back2, o_backs;  // kOptLds entries each (o_backs: x4)
-    OptG *opt_g;          // kNumOpts entries, only those >= kOptLds are used
+    LZ_LDS Rec *o_rec;    // kRecWin slots: price, backPrev, packed path word, backPrev2
+    LZ_LDS Reps *o_bks;   // kBksWin slots: backs0..3
+    uint32_t wlo, wcur, far_hi;  // window start, current cur, highest entry written outside the window
+    OptG *opt_g;          // kNumOpts entries (HBM), always current
     uint8_t *out;         // payload output (after the header)
     uint64_t out_cap;
     MF mf;
@@ -185,35 +208,92 @@ struct Encoder {
     }
 
     // ------------------------------------------------------- optimum table access
-    LZ_HD uint32_t oprice(uint32_t i) const { return i < kOptLds ? o_price[i] : opt_g[i].price; }
-    LZ_HD uint32_t oback(uint32_t i) const { return i < kOptLds ? o_back[i] : opt_g[i].back; }
-    LZ_HD uint32_t opp(uint32_t i) const { return i < kOptLds ? o_pp[i] : opt_g[i].pp; }
-    LZ_HD uint32_t oback2(uint32_t i) const { return i < kOptLds ? o_back2[i] : opt_g[i].back2; }
-    LZ_HD uint32_t obacks(uint32_t i, uint32_t k) const {
-        return i < kOptLds ? o_backs[4 * i + k] : opt_g[i].backs[k];
+    // Writes go to HBM and, inside the window, to LDS; reads inside the window come
+    // from LDS.  Entry i of the window sits in slot i mod kRecWin.
+    // Stores from wave-uniform code are issued by one lane: 64 lanes writing the same
+    // address cost the memory pipeline 64 writes.
+    LZ_HD bool one() const { return lane_id == 0; }
+    LZ_HD bool in_win(uint32_t i) const { return i - wlo < kRecWin; }
+    LZ_HD bool in_bwin(uint32_t i) const { return wcur - i < kBksWin; }
+    LZ_HD Rec grec(uint32_t i) const {
+        Rec r;
+        if (in_win(i)) r = o_rec[i & (kRecWin - 1)]; else r = opt_g[i].rec;
+        return r;
     }
+    LZ_HD Reps gbks(uint32_t i) const {
+        Reps r;
+        if (in_bwin(i)) r = o_bks[i & (kBksWin - 1)]; else r = opt_g[i].bks;
+        return r;
+    }
+    LZ_HD void sbks(uint32_t i, const Reps &v) {  // only ever written at cur
+        opt_g[i].bks = v;
+        o_bks[i & (kBksWin - 1)] = v;
+    }
+    LZ_HD uint32_t oprice(uint32_t i) const {
+        return in_win(i) ? o_rec[i & (kRecWin - 1)].price : opt_g[i].rec.price;
+    }
+    LZ_HD uint32_t opp(uint32_t i) const { return in_win(i) ? o_rec[i & (kRecWin - 1)].pp : opt_g[i].rec.pp; }
     LZ_HD void set_price(uint32_t i, uint32_t v) {
-        if (i < kOptLds) o_price[i] = v; else opt_g[i].price = v;
-    }
-    LZ_HD void set_back(uint32_t i, uint32_t v) {
-        if (i < kOptLds) o_back[i] = v; else opt_g[i].back = v;
+        opt_g[i].rec.price = v;
+        if (in_win(i)) o_rec[i & (kRecWin - 1)].price = v;
     }
     LZ_HD void set_pp(uint32_t i, uint32_t v) {
-        if (i < kOptLds) o_pp[i] = v; else opt_g[i].pp = v;
+        opt_g[i].rec.pp = v;
+        if (in_win(i)) o_rec[i & (kRecWin - 1)].pp = v;
     }
-    LZ_HD void set_back2(uint32_t i, uint32_t v) {
-        if (i < kOptLds) o_back2[i] = v; else opt_g[i].back2 = v;
+    // price, backPrev and path word in one go (backPrev2 keeps its old value)
+    LZ_HD void set_pbp(uint32_t i, uint32_t price, uint32_t back, uint32_t ppw) {
+        opt_g[i].rec.price = price, opt_g[i].rec.back = back, opt_g[i].rec.pp = ppw;
+        if (in_win(i)) {
+            LZ_LDS Rec *r = o_rec + (i & (kRecWin - 1));
+            r->price = price, r->back = back, r->pp = ppw;
+        }
     }
-    LZ_HD void set_backs(uint32_t i, uint32_t k, uint32_t v) {
-        if (i < kOptLds) o_backs[4 * i + k] = v; else opt_g[i].backs[k] = v;
+    LZ_HD void u_set_pp(uint32_t i, uint32_t v) {
+        if (one()) set_pp(i, v);
     }
-    LZ_HD uint32_t ostate(uint32_t i) const { return (opp(i) >> 24) & 0xF; }
+    LZ_HD void u_set_pbp(uint32_t i, uint32_t price, uint32_t back, uint32_t ppw) {
+        if (one()) set_pbp(i, price, back, ppw);
+    }
+    LZ_HD void u_sbks(uint32_t i, const Reps &v) {
+        if (one()) sbks(i, v);
+    }
+    LZ_HD void srec(uint32_t i, const Rec &v) {
+        opt_g[i].rec = v;
+        if (in_win(i)) o_rec[i & (kRecWin - 1)] = v;
+    }
+    // Uniform helpers: loads are issued first and made uniform afterwards, so that
+    // several are in flight at once.
+    static LZ_HD Rec urec(Rec r) {
+        r.price = U(r.price), r.back = U(r.back), r.pp = U(r.pp), r.back2 = U(r.back2);
+        return r;
+    }
+    static LZ_HD Reps ureps(Reps r) {
+        r.r[0] = U(r.r[0]), r.r[1] = U(r.r[1]), r.r[2] = U(r.r[2]), r.r[3] = U(r.r[3]);
+        return r;
+    }
+    LZ_HD uint32_t up0(uint32_t p) const { return U(price0(p)); }
+    LZ_HD uint32_t up1(uint32_t p) const { return U(price1(p)); }
+    // Window bookkeeping when cur advances to c (by one): the entry that enters the
+    // window is fetched from HBM if anything was ever written that far out.
+    LZ_HD void win_advance(uint32_t c) {
+        wcur = c;
+        const uint32_t lo = c > kRecBack ? c - kRecBack : 0;
+        if (lo != wlo) {
+            wlo = lo;
+            const uint32_t e = lo + kRecWin - 1;
+            if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
+        }
+    }
+    LZ_HD void note_far(uint32_t hi) {  // an apply phase wrote entries up to hi
+        if (hi >= wlo + kRecWin && hi > far_hi) far_hi = hi;
+    }
 
     // ------------------------------------------------------------ range coder
     LZ_HD void rc_put(uint32_t b) {
-        if (out_n < out_cap)
-            out[out_n] = (uint8_t)b;
-        else
+        if (out_n < out_cap) {
+            if (one()) out[out_n] = (uint8_t)b;
+        } else
             overflow = 1;
         out_n++;
     }
@@ -232,15 +312,17 @@ struct Encoder {
     }
     template <class P>
     LZ_HD void rc_bit(P pr, uint32_t idx, uint32_t bit) {  // range_coder.go:205-220
-        uint32_t p = pr[idx], bound = (range >> kProbBits) * p;
+        uint32_t p = U(pr[idx]), bound = (range >> kProbBits) * p;
+        uint32_t np;
         if (bit == 0) {
             range = bound;
-            pr[idx] = (prob_t)(p + ((kProbTotal - p) >> kMoveBits));
+            np = p + ((kProbTotal - p) >> kMoveBits);
         } else {
             low += bound;
             range -= bound;
-            pr[idx] = (prob_t)(p - (p >> kMoveBits));
+            np = p - (p >> kMoveBits);
         }
+        if (one()) pr[idx] = (prob_t)np;
         if (range < kTopValue) {
             range <<= 8;
             rc_shift_low();
@@ -313,9 +395,10 @@ struct Encoder {
     // setPrices / updateTable, lzma_len_coder.go:66-88,111-114: one symbol per lane
     LZ_HD void len_set_prices(uint32_t which, uint32_t ps) {
         const uint32_t b = len_base(which), nsym = ep.fb + 1 - kMatchMin;
-        const uint32_t a0 = price0(probs[b + LEN_CHOICE]), a1 = price1(probs[b + LEN_CHOICE]);
-        const uint32_t b0 = a1 + price0(probs[b + LEN_CHOICE + 1]);
-        const uint32_t b1 = a1 + price1(probs[b + LEN_CHOICE + 1]);
+        const uint32_t c0 = U(probs[b + LEN_CHOICE]), c1 = U(probs[b + LEN_CHOICE + 1]);
+        const uint32_t a0 = up0(c0), a1 = up1(c0);
+        const uint32_t b0 = a1 + up0(c1);
+        const uint32_t b1 = a1 + up1(c1);
         auto pr = prices + len_tab(which) + ps * kNumLenSyms;
         LZ_PAR_BEGIN(L)
         for (uint32_t i = L; i < nsym; i += kLanes) {
@@ -329,7 +412,7 @@ struct Encoder {
             pr[i] = (WT)v;
         }
         LZ_PAR_END
-        len_counter[which * kPosStatesMax + ps] = nsym;
+        if (one()) len_counter[which * kPosStatesMax + ps] = nsym;
     }
     LZ_HD void len_encode(uint32_t which, uint32_t sym, uint32_t ps) {  // :48-63, :120-126
         const uint32_t b = len_base(which);
@@ -347,7 +430,9 @@ struct Encoder {
                 bt_encode(probs, b + LEN_HIGH, 8, s - kLenMid);
             }
         }
-        if (--len_counter[which * kPosStatesMax + ps] == 0) len_set_prices(which, ps);
+        const uint32_t left_ = U(len_counter[which * kPosStatesMax + ps]) - 1;
+        if (one()) len_counter[which * kPosStatesMax + ps] = left_;
+        if (left_ == 0) len_set_prices(which, ps);
     }
     LZ_HD uint32_t len_price(uint32_t which, uint32_t sym, uint32_t ps) const {
         return prices[len_tab(which) + ps * kNumLenSyms + sym];
@@ -399,6 +484,7 @@ struct Encoder {
     // ------------------------------------------------------ window access helpers
     LZ_HD uint32_t avail() const { return n - mfpos; }  // getNumAvailableBytes
     LZ_HD uint32_t index_byte(int32_t index) const { return data[(int64_t)mfpos + index]; }
+    LZ_HD uint32_t uindex_byte(int32_t index) const { return U(index_byte(index)); }
     // getMatchLen, lz_window.go:169-182, eight bytes at a time
     LZ_HD uint32_t match_len(int32_t index, uint32_t distance, uint32_t limit) const {
         const uint32_t p = (uint32_t)((int64_t)mfpos + index);
@@ -425,11 +511,12 @@ struct Encoder {
 
     LZ_HD uint32_t read_match_distances() {  // lzma_encoder.go:274-285
         uint32_t res = 0;
-        dist_pairs = 2 * mf(mfpos, mdist);
+        dist_pairs = 2 * U(mf(mfpos, mdist));
         mfpos++;
         if (dist_pairs > 0) {
-            res = mdist[dist_pairs - 2];
-            if (res == ep.fb) res += match_len((int32_t)res - 1, mdist[dist_pairs - 1], kMatchMax - res);
+            res = U(mdist[dist_pairs - 2]);
+            if (res == ep.fb)
+                res += U(match_len((int32_t)res - 1, U(mdist[dist_pairs - 1]), kMatchMax - res));
         }
         add_offset++;
         return res;
@@ -472,99 +559,131 @@ struct Encoder {
         return price0(probs[P_IS_REP_G0 + st]) + price0(probs[P_IS_REP0_LONG + LZ_IDX(st, ps)]);
     }
 
-    LZ_HD uint32_t backward(uint32_t cur) {  // :331-357
+    // backward (:331-357) walks the whole path, most of which has left the window:
+    // it works on the HBM copy alone.  The window is not used again before the next
+    // parse starts from entry 0.
+    LZ_HD uint32_t backward(uint32_t cur) {
+        OptG *o = opt_g;
         opt_end = cur;
-        uint32_t w = opp(cur);
-        uint32_t pos_mem = w & 0xFFF, back_mem = oback(cur);
+        uint32_t w = U(o[cur].rec.pp);
+        uint32_t pos_mem = w & 0xFFF, back_mem = U(o[cur].rec.back);
         do {
-            w = opp(cur);
+            const uint32_t w_v = o[cur].rec.pp, b2_v = o[cur].rec.back2;
+            const uint32_t pm_v = o[pos_mem].rec.pp, pm1_v = o[pos_mem ? pos_mem - 1 : 0].rec.pp;
+            const uint32_t pmb_v = o[pos_mem].rec.back;
+            w = U(w_v);
+            uint32_t wp = U(pm_v), bp = U(pmb_v);
             if (w & kPpPrev1) {
-                set_back(pos_mem, 0xFFFFFFFFu);
-                set_pp(pos_mem, (opp(pos_mem) & ~(0xFFFu | kPpPrev1)) | (pos_mem - 1));
-                if (w & kPpPrev2) {
-                    set_pp(pos_mem - 1, (opp(pos_mem - 1) & ~(0xFFFu | kPpPrev1)) | ((w >> 12) & 0xFFF));
-                    set_back(pos_mem - 1, oback2(cur));
+                bp = 0xFFFFFFFFu;
+                wp = (wp & ~(0xFFFu | kPpPrev1)) | (pos_mem - 1);
+                if ((w & kPpPrev2) && one()) {
+                    o[pos_mem - 1].rec.pp = (U(pm1_v) & ~(0xFFFu | kPpPrev1)) | ((w >> 12) & 0xFFF);
+                    o[pos_mem - 1].rec.back = U(b2_v);
                 }
             }
             const uint32_t pprev = pos_mem, bc = back_mem;
-            back_mem = oback(pprev);
-            const uint32_t wp = opp(pprev);
+            back_mem = bp;
             pos_mem = wp & 0xFFF;
-            set_back(pprev, bc);
-            set_pp(pprev, (wp & ~0xFFFu) | cur);
+            if (one()) {
+                o[pprev].rec.back = bc;
+                o[pprev].rec.pp = (wp & ~0xFFFu) | cur;
+            }
             cur = pprev;
         } while (cur > 0);
-        back_res = oback(0);
-        opt_cur = opp(0) & 0xFFF;
+        back_res = U(o[0].rec.back);
+        opt_cur = U(o[0].rec.pp) & 0xFFF;
         return opt_cur;
     }
 
+    // Uniform inputs of the apply phase, held in registers.
+    struct ApplyIn {
+        uint32_t cur, old_end, new_end, ps, start_len, new_len, nmp, npairs, first_la;
+        uint32_t rl[4], prp[4];  // plain rep candidates: length (< 2 = none), price without length
+        uint32_t lt[5], lp[5];   // continuation of the literal [0] and of rep i [1+i]: target (0 = none), price
+    };
+
     // The apply phase (see the header comment): entries cur+2 .. new_end.
-    //   old_end:   entries beyond it are new and start at infinity
-    //   rep_lens/rep_prp: plain rep candidates (length < 2 = none)
-    //   start_len/new_len/nmp: plain match candidates over mdist[0..npairs) (new_len 0 = none)
-    //   la_*[0], [1..4], [5+first_la..5+npairs): continuation candidates (la_tgt 0 = none);
+    //   old_end: entries beyond it are new and start at infinity
+    //   plain match candidates: lengths start_len..new_len over mdist[0..npairs) (new_len 0 = none)
+    //   continuations of pairs first_la..npairs-1 are in la_tgt/la_price[5+j];
     //   the path words of a continuation follow from the step it continues.
-    LZ_HD void apply(uint32_t cur, uint32_t old_end, uint32_t new_end, uint32_t ps, uint32_t start_len,
-                     uint32_t new_len, uint32_t nmp, uint32_t npairs, uint32_t first_la, bool with_la) {
+    LZ_HD void apply(const ApplyIn &A, bool with_la) {
+        const uint32_t cur = A.cur, ps = A.ps;
+        const uint32_t rl_max = max4(A.rl[0], A.rl[1], A.rl[2], A.rl[3]);
         LZ_PAR_BEGIN(L)
-        for (uint32_t x = cur + 2 + L; x <= new_end; x += kLanes) {
+        for (uint32_t x = cur + 2 + L; x <= A.new_end; x += kLanes) {
             const uint32_t len = x - cur;
-            uint32_t price = x <= old_end ? oprice(x) : kInfPrice;
-            bool changed = x > old_end;
+            uint32_t price = kInfPrice;
+            if (x <= A.old_end) price = oprice(x);
+            // every table value this entry may need, fetched together
+            uint32_t rep_lp = 0, m_price = 0, m_dist = 0;
+            if (len <= rl_max) rep_lp = len_price(1, len - kMatchMin, ps);
+            const bool plain = A.new_len != 0 && len >= A.start_len && len <= A.new_len;
+            if (plain) {
+                uint32_t j = 0;
+                while (mdist[2 * j] < len) j++;
+                m_dist = mdist[2 * j + 1];
+                m_price = A.nmp + pos_len_price(m_dist, len, ps);
+            }
+            bool changed = x > A.old_end;
             uint32_t back = 0, ppw = 0, back2 = 0;
             bool is_la = false;
-            if (with_la && la_tgt[0] == x && la_price[0] < price) {
-                price = la_price[0], back = 0, ppw = (cur + 1) | kPpPrev1, back2 = 0, is_la = true, changed = true;
+            if (with_la && A.lt[0] == x && A.lp[0] < price) {
+                price = A.lp[0], back = 0, ppw = (cur + 1) | kPpPrev1, back2 = 0, is_la = true, changed = true;
             }
+#pragma unroll
             for (uint32_t ri = 0; ri < kNumReps; ri++) {
-                const uint32_t lt = rep_lens[ri];
+                const uint32_t lt = A.rl[ri];
                 if (lt >= 2 && len <= lt) {
-                    const uint32_t p = rep_prp[ri] + len_price(1, len - kMatchMin, ps);
+                    const uint32_t p = A.prp[ri] + rep_lp;
                     if (p < price) price = p, back = ri, ppw = cur, is_la = false, changed = true;
                 }
-                if (with_la && la_tgt[1 + ri] == x && la_price[1 + ri] < price) {
-                    price = la_price[1 + ri], back = 0, back2 = ri;
+                if (with_la && A.lt[1 + ri] == x && A.lp[1 + ri] < price) {
+                    price = A.lp[1 + ri], back = 0, back2 = ri;
                     ppw = (cur + lt + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
                     is_la = true, changed = true;
                 }
             }
             if (with_la)
-                for (uint32_t j = first_la; j < npairs; j++)
+                for (uint32_t j = A.first_la; j < A.npairs; j++)
                     if (la_tgt[5 + j] == x && la_price[5 + j] < price) {
                         price = la_price[5 + j], back = 0, back2 = mdist[2 * j + 1] + kNumReps;
                         ppw = (cur + mdist[2 * j] + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
                         is_la = true, changed = true;
                     }
-            if (new_len != 0 && len >= start_len && len <= new_len) {
-                uint32_t j = 0;
-                while (mdist[2 * j] < len) j++;
-                const uint32_t d = mdist[2 * j + 1];
-                const uint32_t p = nmp + pos_len_price(d, len, ps);
-                if (p < price) price = p, back = d + kNumReps, ppw = cur, is_la = false, changed = true;
-            }
+            if (plain && m_price < price)
+                price = m_price, back = m_dist + kNumReps, ppw = cur, is_la = false, changed = true;
             if (changed) {
-                set_price(x, price);
-                if (price != kInfPrice) {
-                    set_back(x, back);
-                    set_pp(x, ppw);
-                    if (is_la) set_back2(x, back2);
+                if (price == kInfPrice) {
+                    set_price(x, price);
+                } else if (is_la) {
+                    Rec r;
+                    r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
+                    srec(x, r);
+                } else {
+                    set_pbp(x, price, back, ppw);
                 }
             }
         }
         LZ_PAR_END
     }
+    static LZ_HD uint32_t max4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        const uint32_t x = a > b ? a : b, y = c > d ? c : d;
+        return x > y ? x : y;
+    }
 
     LZ_HD uint32_t get_optimum(uint32_t position) {  // :359-797
         const uint32_t fb = ep.fb;
         if (opt_end != opt_cur) {
-            const uint32_t nxt = opp(opt_cur) & 0xFFF;
+            const uint32_t pp_v = opt_g[opt_cur].rec.pp, bk_v = opt_g[opt_cur].rec.back;
+            const uint32_t nxt = U(pp_v) & 0xFFF;
             const uint32_t r = nxt - opt_cur;
-            back_res = oback(opt_cur);
+            back_res = U(bk_v);
             opt_cur = nxt;
             return r;
         }
         opt_end = opt_cur = 0;
+        wlo = 0, wcur = 0, far_hi = 0;
         uint32_t len_main;
         if (!longest_found)
             len_main = read_match_distances();
@@ -580,71 +699,94 @@ struct Encoder {
         // rep lengths and the two bytes the literal needs, in parallel
         LZ_PAR_BEGIN(L)
         if (L < kNumReps) {
-            reps[L] = rep_dist[L];
             rep_lens[L] = match_len(-1, rep_dist[L], kMatchMax);
         } else if (L == 4) {
             xch[0] = index_byte(-1);
             xch[1] = index_byte(0 - (int32_t)rep_dist[0] - 1 - 1);
         }
         LZ_PAR_END
+        uint32_t r0 = U(rep_dist[0]), r1 = U(rep_dist[1]), r2 = U(rep_dist[2]), r3 = U(rep_dist[3]);  // z.reps
+        ApplyIn A;
+        for (uint32_t i = 0; i < kNumReps; i++) A.rl[i] = U(rep_lens[i]);
         uint32_t rep_max = 0;
         for (uint32_t i = 1; i < kNumReps; i++)
-            if (rep_lens[i] > rep_lens[rep_max]) rep_max = i;
-        const uint32_t rep_max_len = rep_lens[rep_max];
+            if (A.rl[i] > A.rl[rep_max]) rep_max = i;
+        const uint32_t rep_max_len = A.rl[rep_max];
         if (rep_max_len >= fb) {
             back_res = rep_max;
             move_pos(rep_max_len - 1);
             return rep_max_len;
         }
         if (len_main >= fb) {
-            back_res = mdist[dpairs - 1] + kNumReps;
+            back_res = U(mdist[dpairs - 1]) + kNumReps;
             move_pos(len_main - 1);
             return len_main;
         }
-        const uint32_t cur_byte0 = xch[0], match_byte0 = xch[1];
+        const uint32_t cur_byte0 = U(xch[0]), match_byte0 = U(xch[1]);
         if (len_main < 2 && cur_byte0 != match_byte0 && rep_max_len < 2) {
             back_res = 0xFFFFFFFFu;
             return 1;
         }
         uint32_t ps = position & pos_state_mask;
-        const uint32_t im0 = probs[P_IS_MATCH + LZ_IDX(state, ps)];
-        uint32_t price1_ = price0(im0) + lit_price(lit_sub(position, prev_byte), !st_is_char(state),
-                                                    match_byte0, cur_byte0);
-        uint32_t back1 = 0xFFFFFFFFu;
-        uint32_t match_price = price1(im0);
-        uint32_t rep_match_price = match_price + price1(probs[P_IS_REP + state]);
-        if (match_byte0 == cur_byte0) {
-            const uint32_t sp = rep_match_price + rep_len1_price(state, ps);
-            if (sp < price1_) {
-                price1_ = sp;
-                back1 = 0;
+        uint32_t rep_len1;
+        uint32_t match_price, rep_match_price, nmp;
+        {
+            const uint32_t im_v = probs[P_IS_MATCH + LZ_IDX(state, ps)], ir_v = probs[P_IS_REP + state];
+            const uint32_t g0_v = probs[P_IS_REP_G0 + state], g1_v = probs[P_IS_REP_G1 + state];
+            const uint32_t g2_v = probs[P_IS_REP_G2 + state], rl_v = probs[P_IS_REP0_LONG + LZ_IDX(state, ps)];
+            const uint32_t im0_v = price0(im_v), im1_v = price1(im_v), ir0_v = price0(ir_v), ir1_v = price1(ir_v);
+            const uint32_t g00_v = price0(g0_v), g01_v = price1(g0_v), g10_v = price0(g1_v), g11_v = price1(g1_v);
+            const uint32_t g20_v = price0(g2_v), g21_v = price1(g2_v), rl0_v = price0(rl_v), rl1_v = price1(rl_v);
+            const uint32_t im0 = U(im0_v), im1 = U(im1_v), ir0 = U(ir0_v), ir1 = U(ir1_v);
+            const uint32_t g00 = U(g00_v), g01 = U(g01_v), g10 = U(g10_v), g11 = U(g11_v);
+            const uint32_t g20 = U(g20_v), g21 = U(g21_v), rl0 = U(rl0_v), rl1 = U(rl1_v);
+            match_price = im1;
+            rep_match_price = match_price + ir1;
+            nmp = match_price + ir0;
+            A.prp[0] = rep_match_price + g00 + rl1;
+            A.prp[1] = rep_match_price + g01 + g10;
+            A.prp[2] = rep_match_price + g01 + g11 + g20;
+            A.prp[3] = rep_match_price + g01 + g11 + g21;
+            rep_len1 = g00 + rl0;
+            uint32_t price1_ = im0 + U(lit_price(lit_sub(position, prev_byte), !st_is_char(state),
+                                                 match_byte0, cur_byte0));
+            uint32_t back1 = 0xFFFFFFFFu;
+            if (match_byte0 == cur_byte0) {
+                const uint32_t sp = rep_match_price + rep_len1;
+                if (sp < price1_) {
+                    price1_ = sp;
+                    back1 = 0;
+                }
             }
+            uint32_t len_end0 = rep_max_len;
+            if (len_main > len_end0) len_end0 = len_main;
+            if (len_end0 < 2) {
+                back_res = back1;
+                return 1;
+            }
+            u_set_pp(0, state << 24);
+            Reps b0;
+            b0.r[0] = r0, b0.r[1] = r1, b0.r[2] = r2, b0.r[3] = r3;
+            u_sbks(0, b0);
+            u_set_pbp(1, price1_, back1, 0);
         }
         uint32_t len_end = rep_max_len;
         if (len_main > len_end) len_end = len_main;
-        if (len_end < 2) {
-            back_res = back1;
-            return 1;
-        }
-        set_pp(0, state << 24);
-        for (uint32_t i = 0; i < 4; i++) set_backs(0, i, reps[i]);
-        set_price(1, price1_);
-        set_back(1, back1);
-        set_pp(1, 0);
         {
-            LZ_PAR_BEGIN(L)
-            if (L < kNumReps) rep_prp[L] = rep_match_price + pure_rep_price(L, state, ps);
-            LZ_PAR_END
-            const uint32_t nmp = match_price + price0(probs[P_IS_REP + state]);
-            const uint32_t start_len = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2;
-            const uint32_t new_len = start_len <= len_main ? mdist[dpairs - 2] : 0;
-            apply(0, 1, len_end, ps, start_len, new_len, nmp, dpairs >> 1, 0, false);
+            A.cur = 0, A.old_end = 1, A.new_end = len_end, A.ps = ps;
+            A.start_len = A.rl[0] >= 2 ? A.rl[0] + 1 : 2;
+            A.new_len = A.start_len <= len_main ? U(mdist[dpairs - 2]) : 0;
+            A.nmp = nmp, A.npairs = dpairs >> 1, A.first_la = 0;
+            for (uint32_t i = 0; i < 5; i++) A.lt[i] = 0, A.lp[i] = 0;
+            apply(A, false);
+            note_far(len_end);
         }
 
         uint32_t cur = 0;
         for (;;) {
             cur++;
             if (cur == len_end) return backward(cur);
+            win_advance(cur);
             LZ_LAP(5)
             uint32_t new_len = read_match_distances();
             LZ_LAP(0)
@@ -655,36 +797,39 @@ struct Encoder {
                 return backward(cur);
             }
             position++;
-            // ---- state and reps of the path that reaches cur (:525-597)
-            const uint32_t cw = opp(cur);
-            uint32_t pos_prev = cw & 0xFFF, st;
+            // ---- state and reps of the path that reaches cur (:525-597).  The entry E the
+            // path comes from always holds the reps to permute (for a literal or short rep it
+            // is cur-1, whose reps are the current ones).
+            const Rec rc_v = o_rec[cur & (kRecWin - 1)], nxr_v = o_rec[(cur + 1) & (kRecWin - 1)];
+            const Rec rc_ = urec(rc_v), nxr = urec(nxr_v);
+            const uint32_t cw = rc_.pp;
+            uint32_t pos_prev = cw & 0xFFF;
             const bool c_p1 = (cw & kPpPrev1) != 0, c_p2 = (cw & kPpPrev2) != 0;
-            const uint32_t c_bp = oback(cur);
+            const uint32_t c_bp = rc_.back;
+            const uint32_t E = (c_p1 && c_p2) ? ((cw >> 12) & 0xFFF) : (c_p1 ? pos_prev - 1 : pos_prev);
+            const uint32_t e_pp_v = opp(E);
+            const Reps eb_v = gbks(E);
+            const uint32_t e_pp = U(e_pp_v);
+            const Reps eb = ureps(eb_v);
+            uint32_t st = (e_pp >> 24) & 0xF;
             if (c_p1) {
                 pos_prev--;
-                if (c_p2) {
-                    st = ostate((cw >> 12) & 0xFFF);
-                    st = oback2(cur) < kNumReps ? st_rep(st) : st_match(st);
-                } else
-                    st = ostate(pos_prev);
+                if (c_p2) st = rc_.back2 < kNumReps ? st_rep(st) : st_match(st);
                 st = st_char(st);
-            } else
-                st = ostate(pos_prev);
+            }
             if (pos_prev == cur - 1) {
                 st = c_bp == 0 ? st_shortrep(st) : st_char(st);
+                r0 = eb.r[0], r1 = eb.r[1], r2 = eb.r[2], r3 = eb.r[3];
             } else {
                 uint32_t pos;
                 if (c_p1 && c_p2) {
-                    pos_prev = (cw >> 12) & 0xFFF;
-                    pos = oback2(cur);
+                    pos = rc_.back2;
                     st = st_rep(st);
                 } else {
                     pos = c_bp;
                     st = pos < kNumReps ? st_rep(st) : st_match(st);
                 }
-                const uint32_t q0 = obacks(pos_prev, 0), q1 = obacks(pos_prev, 1),
-                               q2 = obacks(pos_prev, 2), q3 = obacks(pos_prev, 3);
-                uint32_t r0, r1, r2, r3;
+                const uint32_t q0 = eb.r[0], q1 = eb.r[1], q2 = eb.r[2], q3 = eb.r[3];
                 if (pos < kNumReps) {
                     if (pos == 0) {
                         r0 = q0, r1 = q1, r2 = q2, r3 = q3;
@@ -698,16 +843,38 @@ struct Encoder {
                 } else {
                     r0 = pos - kNumReps, r1 = q0, r2 = q1, r3 = q2;
                 }
-                reps[0] = r0, reps[1] = r1, reps[2] = r2, reps[3] = r3;
             }
-            set_pp(cur, (cw & ~(0xFu << 24)) | (st << 24));
-            for (uint32_t i = 0; i < 4; i++) set_backs(cur, i, reps[i]);
-            const uint32_t cur_price = oprice(cur);
+            u_set_pp(cur, (cw & ~(0xFu << 24)) | (st << 24));
+            {
+                Reps nb;
+                nb.r[0] = r0, nb.r[1] = r1, nb.r[2] = r2, nb.r[3] = r3;
+                u_sbks(cur, nb);
+            }
+            const uint32_t cur_price = rc_.price;
             ps = position & pos_state_mask;
-            const uint32_t is_match_p = probs[P_IS_MATCH + LZ_IDX(st, ps)];
-            match_price = cur_price + price1(is_match_p);
-            rep_match_price = match_price + price1(probs[P_IS_REP + st]);
-            const uint32_t nmp = match_price + price0(probs[P_IS_REP + st]);
+            // every price that depends only on (state, posState): models in one batch, then the
+            // price table in one batch
+            uint32_t p_im0;
+            {
+                const uint32_t im_v = probs[P_IS_MATCH + LZ_IDX(st, ps)], ir_v = probs[P_IS_REP + st];
+                const uint32_t g0_v = probs[P_IS_REP_G0 + st], g1_v = probs[P_IS_REP_G1 + st];
+                const uint32_t g2_v = probs[P_IS_REP_G2 + st], rl_v = probs[P_IS_REP0_LONG + LZ_IDX(st, ps)];
+                const uint32_t im0_v = price0(im_v), im1_v = price1(im_v), ir0_v = price0(ir_v), ir1_v = price1(ir_v);
+                const uint32_t g00_v = price0(g0_v), g01_v = price1(g0_v), g10_v = price0(g1_v), g11_v = price1(g1_v);
+                const uint32_t g20_v = price0(g2_v), g21_v = price1(g2_v), rl0_v = price0(rl_v), rl1_v = price1(rl_v);
+                const uint32_t im0 = U(im0_v), im1 = U(im1_v), ir0 = U(ir0_v), ir1 = U(ir1_v);
+                const uint32_t g00 = U(g00_v), g01 = U(g01_v), g10 = U(g10_v), g11 = U(g11_v);
+                const uint32_t g20 = U(g20_v), g21 = U(g21_v), rl0 = U(rl0_v), rl1 = U(rl1_v);
+                p_im0 = im0;
+                match_price = cur_price + im1;
+                rep_match_price = match_price + ir1;
+                nmp = match_price + ir0;
+                A.prp[0] = rep_match_price + g00 + rl1;
+                A.prp[1] = rep_match_price + g01 + g10;
+                A.prp[2] = rep_match_price + g01 + g11 + g20;
+                A.prp[3] = rep_match_price + g01 + g11 + g21;
+                rep_len1 = g00 + rl0;
+            }
             uint32_t avail_full = kNumOpts - 1 - cur;
             if (avail() + 1 < avail_full) avail_full = avail() + 1;
             const uint32_t av = avail_full < fb ? avail_full : fb;
@@ -716,11 +883,10 @@ struct Encoder {
             if (do_rest && new_len > av) {  // :724-731
                 new_len = av;
                 uint32_t j = 0;
-                while (new_len > mdist[2 * j]) j++;
-                mdist[2 * j] = new_len;
+                while (new_len > U(mdist[2 * j])) j++;
+                if (one()) mdist[2 * j] = new_len;
                 npairs = j + 1;
             }
-
             LZ_LAP(1)
             // ---- the round: every lane runs the same code on its own task.
             //   lanes 0-3: rep match L (:661-663) and its continuation (:689-721)
@@ -735,12 +901,13 @@ struct Encoder {
                 const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
                 const bool is_rep = first && L < kNumReps, is_lit = first && L == 4;
                 const bool is_pair = do_rest && L >= 8 && j < npairs;
-                uint32_t a_off = mfpos - 1, dist = 0, lim1 = 0, lim2 = 0, lt_pair = 0;
+                uint32_t a_off = mfpos - 1, dist = 0, lim1 = 0, lim2 = 0, lt_pair = 0, rprp = 0;
                 if (is_rep) {
-                    dist = reps[L];
+                    dist = L == 0 ? r0 : (L == 1 ? r1 : (L == 2 ? r2 : r3));
+                    rprp = L == 0 ? A.prp[0] : (L == 1 ? A.prp[1] : (L == 2 ? A.prp[2] : A.prp[3]));
                     if (do_rest) lim1 = av;
                 } else if (is_lit) {
-                    dist = reps[0];
+                    dist = r0;
                     if (do_rest) lim2 = avail_full - 1 < fb ? avail_full - 1 : fb;
                 } else if (is_pair) {
                     lt_pair = mdist[2 * j], dist = mdist[2 * j + 1];
@@ -755,22 +922,22 @@ struct Encoder {
                     const uint8_t *b = a - (int64_t)dist - 1;
                     const uint32_t left = n - a_off;  // bytes of the chunk from a on (>= 1)
                     if (a_off + 16 <= readable) {
-                        const uint64_t x0 = enc_load8(a) ^ enc_load8(b), x1 = enc_load8(a + 8) ^ enc_load8(b + 8);
+                        const uint64_t a0 = enc_load8(a), b0 = enc_load8(b), a1 = enc_load8(a + 8), b1 = enc_load8(b + 8);
+                        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
                         const uint32_t pv = a[-1];
                         // equal bytes from offset `from` inside the 16 fetched (16 - from if all equal)
                         auto run16 = [&](uint32_t from) -> uint32_t {
                             if (from >= 16) return 0;
-                            uint64_t lo = x0, hi = x1;
                             if (from >= 8) {
-                                lo = hi >> (8 * (from - 8));
-                                return lo ? (uint32_t)__builtin_ctzll(lo) >> 3 : 16 - from;
+                                const uint64_t hi = x1 >> (8 * (from - 8));
+                                return hi ? (uint32_t)__builtin_ctzll(hi) >> 3 : 16 - from;
                             }
-                            lo >>= 8 * from;
+                            const uint64_t lo = x0 >> (8 * from);
                             if (lo) return (uint32_t)__builtin_ctzll(lo) >> 3;
-                            return (8 - from) + (hi ? (uint32_t)__builtin_ctzll(hi) >> 3 : 8);
+                            return (8 - from) + (x1 ? (uint32_t)__builtin_ctzll(x1) >> 3 : 8);
                         };
                         if (lim1) {
-                            uint32_t lim = lim1 < left ? lim1 : left;
+                            const uint32_t lim = lim1 < left ? lim1 : left;
                             s1 = run16(0);
                             if (s1 == 16 && lim > 16) s1 = 16 + match_len((int32_t)(a_off + 16 - mfpos), dist, lim - 16);
                             if (s1 > lim) s1 = lim;
@@ -780,12 +947,13 @@ struct Encoder {
                             if (is_rep) lim2 = avail_full - 1 - s1 < fb ? avail_full - 1 - s1 : fb;
                             if (s1 < 16) {
                                 const uint32_t sh = 8 * (s1 & 7);
-                                cur_b = (uint32_t)((s1 < 8 ? enc_load8(a) : enc_load8(a + 8)) >> sh) & 0xFF;
-                                match_b = (uint32_t)((s1 < 8 ? enc_load8(b) : enc_load8(b + 8)) >> sh) & 0xFF;
+                                cur_b = (uint32_t)((s1 < 8 ? a0 : a1) >> sh) & 0xFF;
+                                match_b = (uint32_t)((s1 < 8 ? b0 : b1) >> sh) & 0xFF;
+                                const uint32_t shp = 8 * ((s1 - 1) & 7);
+                                prev_b = s1 == 0 ? pv : (uint32_t)((s1 <= 8 ? a0 : a1) >> shp) & 0xFF;
                             } else {
-                                cur_b = a[s1], match_b = b[s1];
+                                cur_b = a[s1], match_b = b[s1], prev_b = a[s1 - 1];
                             }
-                            prev_b = s1 ? a[s1 - 1] : pv;
                             if (lim2) {
                                 const uint32_t from = s1 + 1;
                                 uint32_t lim = left > from ? left - from : 0;
@@ -807,8 +975,6 @@ struct Encoder {
                         }
                     }
                 }
-                uint32_t rprp = 0;
-                if (is_rep) rprp = rep_match_price + pure_rep_price(L, st, ps);
                 uint32_t tgt = 0;
                 if (tail && (is_lit || s2 >= 2)) {
                     const uint32_t lt = is_rep ? s1 : lt_pair;  // 0 for the literal lane
@@ -819,20 +985,22 @@ struct Encoder {
                         xch[0] = cur_b, xch[1] = match_b, xch[2] = litp, xch[3] = s2;
                     } else {
                         const uint32_t s_after = is_rep ? st_rep(st) : st_match(st);
+                        const uint32_t s2s = st_char(s_after);
+                        const uint32_t psn = pos_after & pos_state_mask, psn2 = (pos_after + 1) & pos_state_mask;
+                        // models first, then prices: two batches of loads
+                        const uint32_t m_a = probs[P_IS_MATCH + LZ_IDX(s_after, psn)];
+                        const uint32_t m_b = probs[P_IS_MATCH + LZ_IDX(s2s, psn2)], m_c = probs[P_IS_REP + s2s];
+                        const uint32_t m_d = probs[P_IS_REP_G0 + s2s], m_e = probs[P_IS_REP0_LONG + LZ_IDX(s2s, psn2)];
                         const uint32_t base = is_rep ? rprp + len_price(1, lt - kMatchMin, ps)
                                                      : nmp + pos_len_price(dist, lt, ps);
-                        uint32_t psn = pos_after & pos_state_mask;
-                        uint32_t p = base + price0(probs[P_IS_MATCH + LZ_IDX(s_after, psn)]) + litp;
-                        const uint32_t s2s = st_char(s_after);
-                        psn = (pos_after + 1) & pos_state_mask;
-                        p += price1(probs[P_IS_MATCH + LZ_IDX(s2s, psn)]) + price1(probs[P_IS_REP + s2s]);
-                        p += rep_price(0, s2, s2s, psn);
+                        const uint32_t p = base + price0(m_a) + litp + price1(m_b) + price1(m_c) +
+                                           len_price(1, s2 - kMatchMin, psn2) + price0(m_d) + price1(m_e);
                         tgt = cur + lt + 1 + s2;
                         la_price[is_rep ? 1 + L : 5 + j] = p;
                     }
                 }
                 if (is_rep) {
-                    rep_lens[L] = s1, rep_prp[L] = rprp, la_tgt[1 + L] = tgt;
+                    rep_lens[L] = s1, la_tgt[1 + L] = tgt;
                 } else if (is_lit) {
                     la_tgt[0] = 0;
                 } else if (do_rest && L >= 8 && j < npairs) {
@@ -843,9 +1011,10 @@ struct Encoder {
 
             LZ_LAP(2)
             // ---- literal and short rep into entry cur+1 (:598-624)
-            const uint32_t cur_byte = xch[0], match_byte = xch[1];
-            const uint32_t cur_and1 = cur_price + price0(is_match_p) + xch[2];
-            uint32_t nx_price = oprice(cur + 1);
+            const uint32_t x0_v = xch[0], x1_v = xch[1], x2_v = xch[2], x3_v = xch[3];
+            const uint32_t cur_byte = U(x0_v), match_byte = U(x1_v), lit_l2 = U(x3_v);
+            const uint32_t cur_and1 = cur_price + p_im0 + U(x2_v);
+            uint32_t nx_price = nxr.price;
             bool next_is_char = false, nx_changed = false;
             uint32_t nx_back = 0, nx_pp = 0;
             if (cur_and1 < nx_price) {
@@ -857,57 +1026,64 @@ struct Encoder {
                 if (nx_changed)
                     blocked = false;  // posPrev == cur is not < cur
                 else
-                    blocked = (opp(cur + 1) & 0xFFF) < cur && oback(cur + 1) == 0;
+                    blocked = (nxr.pp & 0xFFF) < cur && nxr.back == 0;
                 if (!blocked) {
-                    const uint32_t sp = rep_match_price + rep_len1_price(st, ps);
+                    const uint32_t sp = rep_match_price + rep_len1;
                     if (sp <= nx_price) {
                         nx_price = sp, nx_back = 0, nx_pp = cur;
                         next_is_char = true, nx_changed = true;
                     }
                 }
             }
-            if (nx_changed) {
-                set_price(cur + 1, nx_price);
-                set_back(cur + 1, nx_back);
-                set_pp(cur + 1, nx_pp);
-            }
+            if (nx_changed) u_set_pbp(cur + 1, nx_price, nx_back, nx_pp);
             if (!do_rest) continue;
 
             // ---- continuation of the literal (:635-658)
+            for (uint32_t i = 0; i < 5; i++) A.lt[i] = 0, A.lp[i] = 0;
             uint32_t new_end = len_end;
             if (!next_is_char && match_byte != cur_byte) {
-                const uint32_t l2 = xch[3];
+                const uint32_t l2 = lit_l2;
                 if (l2 >= 2) {
                     const uint32_t s2 = st_char(st);
                     const uint32_t psn = (position + 1) & pos_state_mask;
-                    const uint32_t nrmp = cur_and1 + price1(probs[P_IS_MATCH + LZ_IDX(s2, psn)]) +
-                                          price1(probs[P_IS_REP + s2]);
-                    la_tgt[0] = cur + 1 + l2;
-                    la_price[0] = nrmp + rep_price(0, l2, s2, psn);
+                    const uint32_t m_a = probs[P_IS_MATCH + LZ_IDX(s2, psn)], m_b = probs[P_IS_REP + s2];
+                    const uint32_t m_c = probs[P_IS_REP_G0 + s2], m_d = probs[P_IS_REP0_LONG + LZ_IDX(s2, psn)];
+                    const uint32_t tail_v = price1(m_a) + price1(m_b) + len_price(1, l2 - kMatchMin, psn) +
+                                            price0(m_c) + price1(m_d);
+                    A.lt[0] = cur + 1 + l2;
+                    A.lp[0] = cur_and1 + U(tail_v);
                     if (cur + 1 + l2 > new_end) new_end = cur + 1 + l2;
                 }
             }
-
-            const uint32_t start_len = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2;
+            {
+                uint32_t v_rl[4], v_lt[4], v_lp[4];
+                for (uint32_t ri = 0; ri < kNumReps; ri++)
+                    v_rl[ri] = rep_lens[ri], v_lt[ri] = la_tgt[1 + ri], v_lp[ri] = la_price[1 + ri];
+                for (uint32_t ri = 0; ri < kNumReps; ri++)
+                    A.rl[ri] = U(v_rl[ri]), A.lt[1 + ri] = U(v_lt[ri]), A.lp[1 + ri] = U(v_lp[ri]);
+            }
+            const uint32_t start_len = A.rl[0] >= 2 ? A.rl[0] + 1 : 2;
             for (uint32_t ri = 0; ri < kNumReps; ri++) {
-                const uint32_t lt = rep_lens[ri];
+                const uint32_t lt = A.rl[ri];
                 if (lt >= 2 && cur + lt > new_end) new_end = cur + lt;
-                const uint32_t tg = la_tgt[1 + ri];
-                if (tg > new_end) new_end = tg;
+                if (A.lt[1 + ri] > new_end) new_end = A.lt[1 + ri];
             }
             uint32_t first_la = npairs, plain_len = 0;
             if (new_len >= start_len) {
                 plain_len = new_len;
                 if (cur + new_len > new_end) new_end = cur + new_len;
                 first_la = 0;
-                while (mdist[2 * first_la] < start_len) first_la++;
+                while (U(mdist[2 * first_la]) < start_len) first_la++;
                 for (uint32_t j = first_la; j < npairs; j++) {
-                    const uint32_t tg = la_tgt[5 + j];
+                    const uint32_t tg = U(la_tgt[5 + j]);
                     if (tg > new_end) new_end = tg;
                 }
             }
+            A.cur = cur, A.old_end = len_end, A.new_end = new_end, A.ps = ps, A.start_len = start_len;
+            A.new_len = plain_len, A.nmp = nmp, A.npairs = npairs, A.first_la = first_la;
             LZ_LAP(3)
-            apply(cur, len_end, new_end, ps, start_len, plain_len, nmp, npairs, first_la, true);
+            apply(A, true);
+            note_far(new_end);
             LZ_LAP(4)
             len_end = new_end;
         }
@@ -970,7 +1146,7 @@ struct Encoder {
             (void)read_match_distances();
             rc_bit(probs, P_IS_MATCH + LZ_IDX(state, now_pos & pos_state_mask), 0);
             state = st_char(state);
-            uint32_t cb = index_byte(0 - (int32_t)add_offset);
+            uint32_t cb = uindex_byte(0 - (int32_t)add_offset);
             lit_encode(lit_sub(now_pos, prev_byte), cb);
             prev_byte = cb;
             add_offset--;
@@ -989,10 +1165,10 @@ struct Encoder {
             uint32_t cs = LZ_IDX(state, ps);
             if (len == 1 && pos == 0xFFFFFFFFu) {
                 rc_bit(probs, P_IS_MATCH + cs, 0);
-                uint32_t cb = index_byte(0 - (int32_t)add_offset);
+                uint32_t cb = uindex_byte(0 - (int32_t)add_offset);
                 uint32_t sub = lit_sub(now_pos, prev_byte);
                 if (!st_is_char(state)) {
-                    uint32_t mb = index_byte(0 - (int32_t)rep_dist[0] - 1 - (int32_t)add_offset);
+                    uint32_t mb = uindex_byte(0 - (int32_t)U(rep_dist[0]) - 1 - (int32_t)add_offset);
                     lit_encode_matched(sub, mb, cb);
                 } else
                     lit_encode(sub, cb);
@@ -1020,9 +1196,9 @@ struct Encoder {
                         len_encode(1, len - kMatchMin, ps);
                         state = st_rep(state);
                     }
-                    uint32_t d = rep_dist[pos];
+                    uint32_t d = U(rep_dist[pos]);
                     if (pos != 0) {
-                        for (uint32_t i = pos; i >= 1; i--) rep_dist[i] = rep_dist[i - 1];
+                        for (uint32_t i = pos; i >= 1; i--) rep_dist[i] = U(rep_dist[i - 1]);
                         rep_dist[0] = d;
                     }
                 } else {
@@ -1044,11 +1220,11 @@ struct Encoder {
                             align_price_count++;
                         }
                     }
-                    for (uint32_t i = kNumReps - 1; i >= 1; i--) rep_dist[i] = rep_dist[i - 1];
+                    for (uint32_t i = kNumReps - 1; i >= 1; i--) rep_dist[i] = U(rep_dist[i - 1]);
                     rep_dist[0] = pos;
                     match_price_count++;
                 }
-                prev_byte = index_byte((int32_t)len - 1 - (int32_t)add_offset);
+                prev_byte = uindex_byte((int32_t)len - 1 - (int32_t)add_offset);
             }
             add_offset -= len;
             now_pos += len;
@@ -1085,7 +1261,7 @@ struct Encoder {
         state = 0;
         prev_byte = 0;
         back_res = 0;
-        for (int i = 0; i < 4; i++) rep_dist[i] = reps[i] = rep_lens[i] = 0;
+        for (int i = 0; i < 4; i++) rep_dist[i] = rep_lens[i] = 0;
         pos_state_mask = (1u << ep.pb) - 1;
         lit_pos_mask = (1u << ep.lp) - 1;
         pl = price_layout(ep.pb);

@@ -100,7 +100,9 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     std::vector<lz::prob_t> probs(lz::kNumBaseProbs + ((size_t)0x300 << (lc + lp)), lz::kProbInit);
     std::vector<uint16_t> prices(lz::price_layout(pb).total, 0), pp(512);
     std::vector<lz::OptG> opt_g(lz::kNumOpts);
-    std::vector<uint32_t> opt_l(8 * lz::kOptLds), small(lz::kEncSmallWords);
+    std::vector<lz::Rec> opt_rec(lz::kRecWin);
+    std::vector<lz::Reps> opt_bks(lz::kBksWin);
+    std::vector<uint32_t> small(lz::kEncSmallWords);
     lz::build_prob_prices(pp.data(), 0, 1);
     lz::Encoder<ChainMFRef, lz::prob_t *> e;
     e.data = padded.data();
@@ -110,11 +112,8 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     e.lit = probs.data() + lz::P_LIT;
     e.prices = prices.data();
     e.pp = pp.data();
-    e.o_price = opt_l.data();
-    e.o_back = e.o_price + lz::kOptLds;
-    e.o_pp = e.o_back + lz::kOptLds;
-    e.o_back2 = e.o_pp + lz::kOptLds;
-    e.o_backs = e.o_back2 + lz::kOptLds;
+    e.o_rec = opt_rec.data();
+    e.o_bks = opt_bks.data();
     e.opt_g = opt_g.data();
     e.out = out + lz::kHeaderSize;
     e.out_cap = out_cap - lz::kHeaderSize;
