@@ -87,13 +87,21 @@ LZ_D uint32_t mf_extend(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q,
     return l < limit ? l : limit;
 }
 
+LZ_D uint32_t mf_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+LZ_D uint64_t mf_u64(uint64_t v) { return ((uint64_t)mf_u32((uint32_t)(v >> 32)) << 32) | mf_u32((uint32_t)v); }
+
 // Match list of position P of the job [job_start, job_end).  Called by all 64 lanes
-// of a wave with identical arguments; emit(k, length, distance-1) is called once per
-// pair, k = 0, 1, ... (identically on every lane); returns the number of pairs.
-// A later emit with a smaller k overwrites (the reference drops seed pairs that way).
+// of a wave with identical arguments (inf = t.info[P], fetched by the caller ahead of
+// time); emit(k, length, distance-1) is called once per pair, k = 0, 1, ... (identically
+// on every lane); returns the number of pairs.  A later emit with a smaller k overwrites
+// (the reference drops seed pairs that way).
+//
+// Everything that can be addressed from inf -- P's own two table entries, the 64
+// newest entries of its bucket and of its 8-gram group, the two seed bytes -- is
+// requested in one batch, so a typical position costs one memory round trip.
 template <class Emit>
-LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_t job_end,
-                      Emit emit, uint32_t lane) {
+LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, const MfInfo &inf, uint32_t job_start,
+                      uint32_t job_end, Emit emit, uint32_t lane) {
     const uint32_t left = job_end - P;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
     if (len_limit < 4) return 0;  // lz_bin_tree.go:121-124
@@ -101,27 +109,38 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
     // candidate Q is inside the window iff P - Q <= dict (cyclicBufSize = dict+1, :128-131)
     uint32_t W = P > t.dict ? P - t.dict : 0;
     if (W < job_start) W = job_start;
+    const bool use8 = t.use8 && len_limit >= 8;
 
-    const MfInfo inf = t.info[P];
-    const uint32_t r4 = inf.rank4;
-    const MfEnt me4 = t.ent4[r4];
-    const uint32_t g4 = me4.gstart;
-    const uint64_t p8 = me4.sig;  // P's first 8 bytes
+    // ---- one batch of loads
+    const uint32_t r4 = inf.rank4, r8 = inf.rank8, q2 = inf.prev2, q3 = inf.prev3;
+    const MfEnt me4_v = t.ent4[r4];
+    MfEnt me8_v = me4_v, a0, b0;
+    a0.pos = 0, a0.gstart = 0, a0.sig = 0;
+    b0 = a0;
+    if (use8) me8_v = t.ent8[r8];
+    if (r4 > lane) a0 = t.ent4[r4 - 1 - lane];
+    if (use8 && r8 > lane) b0 = t.ent8[r8 - 1 - lane];
+    uint32_t b2_v = 0x100, b3_v = 0x100;
+    if (q2 != kNone && q2 >= W) b2_v = data[q2];
+    if (q3 != kNone && q3 >= W) b3_v = data[q3];
+
+    const uint32_t g4 = mf_u32(me4_v.gstart);
+    const uint64_t p8 = mf_u64(me4_v.sig);  // P's first 8 bytes
     uint32_t q4 = kNone;
     if (r4 > g4) {
-        q4 = t.ent4[r4 - 1].pos;
+        q4 = (uint32_t)__builtin_amdgcn_readlane((int)a0.pos, 0);
         if (q4 < job_start) q4 = kNone;
     }
-    const uint32_t q2 = inf.prev2, q3 = inf.prev3;
-    const uint32_t b0 = (uint32_t)p8 & 0xFF;
+    const uint32_t b0byte = (uint32_t)p8 & 0xFF;
+    const uint32_t b2 = mf_u32(b2_v), b3 = mf_u32(b3_v);
     uint32_t n = 0, max_len = 1, last = q2;
     // seeds, lz_bin_tree.go:154-180
-    if (q2 != kNone && q2 >= W && data[q2] == b0) {
+    if (b2 == b0byte) {
         max_len = 2;
         emit(0u, 2u, P - q2 - 1);
         n = 1;
     }
-    if (q3 != kNone && q3 >= W && data[q3] == b0) {
+    if (b3 == b0byte) {
         if (q3 == q2) n--;
         max_len = 3;
         emit(n, 3u, P - q3 - 1);
@@ -134,15 +153,13 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
     }
 
     // newest position sharing P's first 8 bytes
-    uint32_t qstar = kNone, r8 = 0, g8 = 0;
+    uint32_t qstar = kNone, g8 = 0;
     uint64_t pn8 = 0;
-    if (t.use8 && len_limit >= 8) {
-        r8 = inf.rank8;
-        const MfEnt me8 = t.ent8[r8];
-        g8 = me8.gstart;
-        pn8 = me8.sig;  // P's bytes 8..15
+    if (use8) {
+        g8 = mf_u32(me8_v.gstart);
+        pn8 = mf_u64(me8_v.sig);  // P's bytes 8..15
         if (r8 > g8) {
-            uint32_t q = t.ent8[r8 - 1].pos;
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)b0.pos, 0);
             if (q >= W) qstar = q;
         }
     }
@@ -153,7 +170,8 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
         bool valid = base > g4 + lane;  // index base-1-lane is still inside the bucket
         uint32_t Q = 0, l = 0;
         if (valid) {
-            const MfEnt e = t.ent4[base - 1 - lane];
+            MfEnt e = a0;
+            if (base != r4) e = t.ent4[base - 1 - lane];
             Q = e.pos;
             valid = Q >= low_a;
             const uint64_t x = e.sig ^ p8;
@@ -181,7 +199,8 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, uint32_t job_start, uint32_
         bool valid = base > g8 + lane;
         uint32_t Q = 0, l = 0;
         if (valid) {
-            const MfEnt e = t.ent8[base - 1 - lane];
+            MfEnt e = b0;
+            if (base != r8) e = t.ent8[base - 1 - lane];
             Q = e.pos;
             valid = Q >= W;
             const uint64_t y = e.sig ^ pn8;

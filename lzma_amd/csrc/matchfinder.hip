@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint
         }
         uint32_t job = lo;
         uint32_t js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
+        lz::MfInfo inf_next = t.info[p_begin];
         for (uint32_t P = p_begin; P < p_end; P++) {
+            lz::MfInfo inf = inf_next;
+            inf.rank4 = lz::mf_u32(inf.rank4), inf.rank8 = lz::mf_u32(inf.rank8);
+            inf.prev2 = lz::mf_u32(inf.prev2), inf.prev3 = lz::mf_u32(inf.prev3);
+            if (P + 1 < p_end) inf_next = t.info[P + 1];
             while (P >= je) {  // empty jobs are skipped
                 job++;
                 js = je;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint
                     dst[2 * k + 1] = dist;
                 }
             };
-            const uint32_t c = lz::mf_find(t, P, js, je, emit, lane);
+            const uint32_t c = lz::mf_find(t, P, inf, js, je, emit, lane);
             if (lane == 0) meta[P] = lz::mf_meta(cursor, c);
             if (!overflow) cursor += c;
             emitted += c;
