@@ -1,0 +1,55 @@
+"""Sharding of independent chunks/streams over one process per GPU.
+
+Chunks are independent .lzma streams, so ranks own contiguous chunk ranges and the
+data path needs no collective.  The only exchange is an all-gather of the per-chunk
+compressed sizes: from it every rank derives where its streams go in the shared
+container (the concatenation of all streams in chunk order), so ranks can write
+their part without further coordination.  The collective runs over whatever
+backend the process group was created with (RCCL on the GPUs, gloo in CPU tests).
+"""
+import torch
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous [begin, end) of `n_items` owned by `rank`; sizes differ by at most one."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} of {world}")
+    base, extra = divmod(int(n_items), world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_counts(n_items: int, world: int):
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def gather_sizes(local_sizes: torch.Tensor, n_items: int, rank: int, world: int, group=None):
+    """All ranks' per-chunk sizes in chunk order (int64 tensor of n_items on local_sizes' device).
+
+    local_sizes holds the sizes of this rank's shard_range(n_items, rank, world).
+    """
+    local_sizes = local_sizes.to(torch.int64)
+    if world == 1:
+        return local_sizes
+    import torch.distributed as dist
+    counts = shard_counts(n_items, world)
+    if local_sizes.numel() != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local_sizes.numel()} sizes, its shard has {counts[rank]}")
+    width = max(counts)
+    if all(c == width for c in counts):
+        out = torch.empty(world * width, dtype=torch.int64, device=local_sizes.device)
+        dist.all_gather_into_tensor(out, local_sizes.contiguous(), group=group)
+        return out
+    # ragged shards: pad to the widest, gather, drop the padding
+    padded = torch.zeros(width, dtype=torch.int64, device=local_sizes.device)
+    padded[: counts[rank]] = local_sizes
+    out = torch.empty(world * width, dtype=torch.int64, device=local_sizes.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * width: r * width + counts[r]] for r in range(world)])
+
+
+def container_offsets(all_sizes: torch.Tensor):
+    """Exclusive prefix sum: offsets[i] = where stream i starts; offsets[-1] = container size."""
+    off = torch.zeros(all_sizes.numel() + 1, dtype=torch.int64, device=all_sizes.device)
+    torch.cumsum(all_sizes, 0, out=off[1:])
+    return off
