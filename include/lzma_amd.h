@@ -134,8 +134,14 @@ int lzma_amd_parse_header(const uint8_t *in, size_t n, uint32_t *lc, uint32_t *l
                           uint32_t *dict_size, int64_t *unpack_size);
 
 /* Milliseconds of device time (hipEvent) spent in the kernels of the calling
- * thread's most recent *_dev call, by phase; any pointer may be NULL. */
+ * thread's most recent *_dev call; any pointer may be NULL.  ms_total is the
+ * span from the first to the last kernel; ms_finder and ms_coder are sums over
+ * the match-finder batches and over the coder launches.  The encoder overlaps
+ * its phases and runs several coder launches at once, so the sums exceed the
+ * span.  No counterpart in the reference (measurement only). */
 void lzma_amd_last_timing(float *ms_total, float *ms_finder, float *ms_coder);
+/* Number of coder kernel launches ms_coder sums over (0 for the finder). */
+int lzma_amd_last_coder_launches(void);
 
 #ifdef __cplusplus
 }

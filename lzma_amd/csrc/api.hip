@@ -7,7 +7,7 @@
 namespace lzh {
 
 ThreadState &tls() {
-    static thread_local ThreadState s = {{0}, 0.f, 0.f, 0.f};
+    static thread_local ThreadState s = {{0}, 0.f, 0.f, 0.f, 0};
     return s;
 }
 
@@ -72,5 +72,7 @@ void lzma_amd_last_timing(float *ms_total, float *ms_finder, float *ms_coder) {
     if (ms_finder) *ms_finder = lzh::tls().ms_finder;
     if (ms_coder) *ms_coder = lzh::tls().ms_coder;
 }
+
+int lzma_amd_last_coder_launches(void) { return lzh::tls().coder_launches; }
 
 }  // extern "C"

@@ -88,6 +88,7 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
                                          int32_t *d_status, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     lzh::tls().ms_total = lzh::tls().ms_finder = lzh::tls().ms_coder = 0.f;
+    lzh::tls().coder_launches = 0;
     if (n_streams == 0) return LZMA_AMD_OK;
     if (!d_in || !d_in_off || !d_out || !d_out_off || !d_out_sizes || !d_status)
         return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
@@ -120,6 +121,7 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     tm.stop();
     LZ_HIP(hipStreamSynchronize(st));
     lzh::tls().ms_total = lzh::tls().ms_coder = tm.ms();
+    lzh::tls().coder_launches = n_big > 0 ? 2 : 1;
     return LZMA_AMD_OK;
 }
 

@@ -15,6 +15,8 @@
 //
 // Roofline class: HBM in principle (N bytes in, C bytes out per chunk);
 // serial-dependency-bound in practice.
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -155,6 +157,8 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
     }
 }
 
+
+
 int check_params(const lzma_amd_params *p) {  // checkValues, lzma_encoder.go:110-129
     if (!p) return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: null params");
     if (p->dict_log < 12 || p->dict_log > 29)
@@ -169,17 +173,52 @@ int check_params(const lzma_amd_params *p) {  // checkValues, lzma_encoder.go:11
     return LZMA_AMD_OK;
 }
 
-constexpr uint64_t kMaxBatchBytes = 1ull << 30;  // positions per match-finder build
+constexpr uint64_t kMaxChunkBytes = 1ull << 30;  // largest single chunk
+constexpr unsigned kChainsPerCU = 7;              // encode workgroups a CU holds (LDS-limited)
+constexpr unsigned kNumCU = 256;
+constexpr int kEncStreams = 3;                    // encode launches in flight
+
+// Everything one batch in flight owns.
+struct Slot {
+    lzh::MfResult res;
+    lzh::DevBuf opt, lit;
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // around the batch's encode launch
+    bool busy = false;
+    ~Slot() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+// The device gives a process four hardware queues: one for the finder and three for
+// encode launches, the caller's stream being one of the three (streams beyond that
+// would share a queue and run one after the other).
+struct Streams {
+    hipStream_t mf = nullptr, enc[kEncStreams] = {};
+    hipEvent_t in_ready = nullptr;
+    ~Streams() {
+        if (mf) (void)hipStreamDestroy(mf);
+        for (int i = 1; i < kEncStreams; i++)  // enc[0] is the caller's
+            if (enc[i]) (void)hipStreamDestroy(enc[i]);
+        if (in_ready) (void)hipEventDestroy(in_ready);
+    }
+};
 
 }  // namespace
 
+// The call is cut into batches of whole chunks.  The finder works through the batches on
+// one stream; each batch's encode launch goes to one of kEncStreams other streams as soon
+// as its match lists are complete, so that up to kEncStreams launches (together about
+// kChainsPerCU chunks per CU) run while the finder prepares the next batch.
 extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off,
                                           size_t n_chunks, size_t in_total, const lzma_amd_params *p,
                                           uint8_t *d_out, const uint64_t *d_out_off,
                                           uint64_t *d_out_sizes, int32_t *d_status, void *stream) {
     (void)in_total;
     hipStream_t st = (hipStream_t)stream;
-    lzh::tls().ms_total = lzh::tls().ms_finder = lzh::tls().ms_coder = 0.f;
+    lzh::ThreadState &ts = lzh::tls();
+    ts.ms_total = ts.ms_finder = ts.ms_coder = 0.f;
+    ts.coder_launches = 0;
     int rc = check_params(p);
     if (rc) return rc;
     if (n_chunks == 0) return LZMA_AMD_OK;
@@ -190,57 +229,115 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     LZ_HIP(hipStreamSynchronize(st));
     for (size_t c = 0; c < n_chunks; c++) {
         if (off[c + 1] < off[c]) return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: offsets must be non-decreasing");
-        if (off[c + 1] - off[c] > kMaxBatchBytes)
+        if (off[c + 1] - off[c] > kMaxChunkBytes)
             return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: chunk %zu larger than %llu bytes", c,
-                             (unsigned long long)kMaxBatchBytes);
+                             (unsigned long long)kMaxChunkBytes);
     }
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
     const LdsLayout L = lds_layout(p->pb);
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
 
-    float ms_finder = 0.f, ms_coder = 0.f;
-    size_t c0 = 0;
-    while (c0 < n_chunks) {
-        size_t c1 = c0 + 1;
-        while (c1 < n_chunks && off[c1 + 1] - off[c0] <= kMaxBatchBytes) c1++;
+    // resident workgroups on the whole device, fewer if the literal models are large
+    unsigned resident = kNumCU * kChainsPerCU;
+    const uint64_t lit_budget = 2ull << 30;
+    if ((uint64_t)resident * lit_stride * sizeof(lz::prob_t) > lit_budget)
+        resident = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
+
+    // batches: whole chunks, at most batch_bytes each (a larger chunk is a batch of its own)
+    const uint64_t total = off[n_chunks] - off[0];
+    uint64_t batch_bytes = 576ull << 20;
+    int enc_streams = kEncStreams;
+    if (const char *e = getenv("LZMA_AMD_BATCH_MIB")) batch_bytes = (uint64_t)atoi(e) << 20;
+    if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
+    std::vector<size_t> cut{0};
+    for (size_t c = 0; c < n_chunks;) {
+        size_t c1 = c + 1;
+        while (c1 < n_chunks && off[c1 + 1] - off[c] <= batch_bytes) c1++;
+        cut.push_back(c1);
+        c = c1;
+    }
+    const size_t nbatches = cut.size() - 1;
+    uint64_t max_bytes = 0;
+    size_t max_chunks = 0;
+    for (size_t b = 0; b < nbatches; b++) {
+        max_bytes = std::max<uint64_t>(max_bytes, off[cut[b + 1]] - off[cut[b]]);
+        max_chunks = std::max(max_chunks, cut[b + 1] - cut[b]);
+    }
+    (void)total;
+    const unsigned in_flight = (unsigned)std::min<size_t>(nbatches, enc_streams);
+    const unsigned grid_cap = std::max(1u, resident / in_flight);
+    const unsigned max_grid = (unsigned)std::min<size_t>(max_chunks, grid_cap);
+
+    Streams S;
+    LZ_HIP(hipStreamCreateWithFlags(&S.mf, hipStreamNonBlocking));
+    S.enc[0] = st;
+    for (int i = 1; i < (int)in_flight; i++) LZ_HIP(hipStreamCreateWithFlags(&S.enc[i], hipStreamNonBlocking));
+    LZ_HIP(hipEventCreateWithFlags(&S.in_ready, hipEventDisableTiming));
+    // whatever the caller enqueued on its stream (the inputs) comes first
+    LZ_HIP(hipEventRecord(S.in_ready, st));
+    LZ_HIP(hipStreamWaitEvent(S.mf, S.in_ready, 0));
+    for (int i = 1; i < (int)in_flight; i++) LZ_HIP(hipStreamWaitEvent(S.enc[i], S.in_ready, 0));
+
+    // all memory up front: nothing is allocated or freed while launches are in flight
+    lzh::MfScratch scratch;
+    if ((rc = scratch.reserve((uint32_t)max_bytes))) return rc;
+    const int nslots = (int)std::min<size_t>(nbatches, in_flight + 1);
+    std::vector<Slot> slots(nslots);
+    for (auto &sl : slots) {
+        if ((rc = sl.res.reserve((uint32_t)max_bytes))) return rc;
+        LZ_HIP(sl.opt.alloc((size_t)max_grid * lz::kNumOpts * sizeof(lz::OptG)));
+        LZ_HIP(sl.lit.alloc((size_t)max_grid * lit_stride * sizeof(lz::prob_t)));
+        LZ_HIP(hipEventCreate(&sl.e0));
+        LZ_HIP(hipEventCreate(&sl.e1));
+    }
+    lzh::Timer t_all;
+    t_all.start(S.mf);
+    std::vector<lzh::Timer> t_mf(nbatches);
+    float ms_coder = 0.f;
+    auto retire = [&](Slot &sl) -> int {
+        if (!sl.busy) return LZMA_AMD_OK;
+        LZ_HIP(hipEventSynchronize(sl.e1));
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sl.e0, sl.e1) == hipSuccess) ms_coder += t;
+        sl.busy = false;
+        return LZMA_AMD_OK;
+    };
+    for (size_t b = 0; b < nbatches; b++) {
+        Slot &sl = slots[b % nslots];
+        if ((rc = retire(sl))) return rc;  // its previous batch must be encoded before its lists go
+        const size_t c0 = cut[b], c1 = cut[b + 1];
         const uint64_t base = off[c0];
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
         const uint32_t nchunks = (uint32_t)(c1 - c0);
-        lzh::Timer t_mf, t_enc;
-        t_mf.start(st);
-        lzh::MfWorkspace ws;
-        rc = ws.build(d_in + base, nbytes, ep.dict_size, ep.fb, st);
-        if (rc) return rc;
+        t_mf[b].start(S.mf);
+        if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf))) return rc;
         uint64_t total_pairs = 0;
-        rc = ws.scan(d_in_off, base, c0, nchunks, st, &total_pairs);
-        if (rc) return rc;
-        t_mf.stop();
-        // resident workgroups: eight per CU, fewer if the literal models are large
-        unsigned grid = nchunks;
-        unsigned max_grid = 256u * 8u;
-        const uint64_t lit_budget = 2ull << 30;
-        if ((uint64_t)max_grid * lit_stride * sizeof(lz::prob_t) > lit_budget)
-            max_grid = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
-        if (grid > max_grid) grid = max_grid;
-        lzh::DevBuf opt, lit;
-        LZ_HIP(opt.alloc((size_t)grid * lz::kNumOpts * sizeof(lz::OptG)));
-        LZ_HIP(lit.alloc((size_t)grid * lit_stride * sizeof(lz::prob_t)));
-        t_enc.start(st);
-        hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), L.total, st, d_in + base, nbytes,
-                           ws.d_meta(), ws.d_arena(), d_in_off, base, (uint64_t)c0, nchunks, ep, d_out,
-                           d_out_off, d_out_sizes, d_status, opt.as<lz::OptG>(), lit.as<lz::prob_t>(),
+        if ((rc = lzh::mf_scan(scratch, sl.res, d_in_off, base, c0, nchunks, S.mf, &total_pairs))) return rc;
+        t_mf[b].stop();
+        // the finder stream is idle here (mf_scan synchronized it): the lists are complete
+        hipStream_t es = S.enc[b % in_flight];
+        const unsigned grid = std::min(nchunks, grid_cap);
+        LZ_HIP(hipEventRecord(sl.e0, es));
+        hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), L.total, es, d_in + base, nbytes,
+                           sl.res.d_meta(), sl.res.d_arena(), d_in_off, base, (uint64_t)c0, nchunks, ep, d_out,
+                           d_out_off, d_out_sizes, d_status, sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(),
                            lit_stride);
-        t_enc.stop();
         LZ_HIP(hipGetLastError());
-        LZ_HIP(hipStreamSynchronize(st));
-        ms_finder += t_mf.ms();
-        ms_coder += t_enc.ms();
-        c0 = c1;
+        LZ_HIP(hipEventRecord(sl.e1, es));
+        sl.busy = true;
+        ts.coder_launches++;
     }
-    lzh::tls().ms_finder = ms_finder;
-    lzh::tls().ms_coder = ms_coder;
-    lzh::tls().ms_total = ms_finder + ms_coder;
+    for (auto &sl : slots)
+        if ((rc = retire(sl))) return rc;
+    t_all.stop();
+    LZ_HIP(hipStreamSynchronize(S.mf));
+    for (int i = 0; i < (int)in_flight; i++) LZ_HIP(hipStreamSynchronize(S.enc[i]));
+    float ms_finder = 0.f;
+    for (auto &t : t_mf) ms_finder += t.ms();
+    ts.ms_finder = ms_finder;
+    ts.ms_coder = ms_coder;
+    ts.ms_total = t_all.ms();
     return LZMA_AMD_OK;
 }
 

@@ -708,10 +708,11 @@ struct Encoder {
         uint32_t r0 = U(rep_dist[0]), r1 = U(rep_dist[1]), r2 = U(rep_dist[2]), r3 = U(rep_dist[3]);  // z.reps
         ApplyIn A;
         for (uint32_t i = 0; i < kNumReps; i++) A.rl[i] = U(rep_lens[i]);
-        uint32_t rep_max = 0;
+        // (no indexing by a variable: that would put the whole struct in scratch memory)
+        uint32_t rep_max = 0, rep_max_len = A.rl[0];
+#pragma unroll
         for (uint32_t i = 1; i < kNumReps; i++)
-            if (A.rl[i] > A.rl[rep_max]) rep_max = i;
-        const uint32_t rep_max_len = A.rl[rep_max];
+            if (A.rl[i] > rep_max_len) rep_max = i, rep_max_len = A.rl[i];
         if (rep_max_len >= fb) {
             back_res = rep_max;
             move_pos(rep_max_len - 1);

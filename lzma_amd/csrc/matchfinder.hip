@@ -109,28 +109,52 @@ unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 256 * 32) {
     return (unsigned)(g < max_blocks ? g : max_blocks);
 }
 
+// Sort configuration: the merge-sort path of the library's radix sort for every size.
+// Its default for large inputs, the single-pass ("onesweep") radix sort, makes no progress
+// while an encode kernel of another stream is resident (measured: its first pass sits
+// until the first encode workgroup exits, about 5 s, whatever its workgroup size), which
+// would serialize the finder/encoder pipeline; the merge path runs next to it unhindered.
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                           rocprim::default_config, ~(size_t)0>;
+
 template <class K>
-int sort_by_key(K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n, unsigned end_bit,
-                hipStream_t st) {
+size_t sort_temp_bytes(uint32_t n, unsigned end_bit) {
     rocprim::counting_iterator<uint32_t> iota(0);
     size_t bytes = 0;
-    LZ_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
+    (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, (K *)nullptr, (K *)nullptr, iota, (uint32_t *)nullptr, n,
+                                    0, end_bit, (hipStream_t) nullptr);
+    return bytes;
+}
+
+size_t scan_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, n,
+                                  rocprim::maximum<uint32_t>(), (hipStream_t) nullptr);
+    return bytes;
+}
+
+template <class K>
+int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n,
+                unsigned end_bit, hipStream_t st) {
+    rocprim::counting_iterator<uint32_t> iota(0);
+    size_t bytes = 0;
+    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
                                      st));
-    lzh::DevBuf temp;
-    LZ_HIP(temp.alloc(bytes));
-    LZ_HIP(rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
+    int rc = s.need_temp(bytes);
+    if (rc) return rc;
+    bytes = s.temp.bytes;
+    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp.p, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
                                      st));
-    LZ_HIP(hipStreamSynchronize(st));  // temp is released at scope exit
     return LZMA_AMD_OK;
 }
 
-int max_scan(uint32_t *io, uint32_t n, hipStream_t st) {
+int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
     size_t bytes = 0;
     LZ_HIP(rocprim::inclusive_scan(nullptr, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
-    lzh::DevBuf temp;
-    LZ_HIP(temp.alloc(bytes));
-    LZ_HIP(rocprim::inclusive_scan(temp.p, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
-    LZ_HIP(hipStreamSynchronize(st));
+    int rc = s.need_temp(bytes);
+    if (rc) return rc;
+    bytes = s.temp.bytes;
+    LZ_HIP(rocprim::inclusive_scan(s.temp.p, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
     return LZMA_AMD_OK;
 }
 
@@ -233,13 +257,37 @@ __global__ __launch_bounds__(256) void mf_counts_kernel(const uint64_t *__restri
 
 namespace lzh {
 
-int MfWorkspace::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb,
-                       hipStream_t st) {
-    const uint32_t mask = lz::bt4_hash_mask(dict_size);
+int MfScratch::need_temp(size_t bytes) {
+    if (bytes <= temp.bytes) return LZMA_AMD_OK;
+    // rare: the estimate made in reserve() was too small (hipFree waits for the device)
+    LZ_HIP(hipDeviceSynchronize());
+    LZ_HIP(temp.alloc(bytes + bytes / 8));
+    return LZMA_AMD_OK;
+}
+
+int MfScratch::reserve(uint32_t n) {
+    if (n <= cap && cap != 0) return LZMA_AMD_OK;
     const size_t n1 = n ? n : 1;
     LZ_HIP(ent4.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(ent8.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
+    LZ_HIP(kin.alloc(n1 * 8));  // sized for the 64-bit keys
+    LZ_HIP(kout.alloc(n1 * 8));
+    LZ_HIP(vout.alloc(n1 * 4));
+    LZ_HIP(grp.alloc(n1 * 4));
+    size_t t = sort_temp_bytes<uint64_t>((uint32_t)n1, 64);
+    const size_t t32 = sort_temp_bytes<uint32_t>((uint32_t)n1, 32), ts = scan_temp_bytes((uint32_t)n1);
+    if (t32 > t) t = t32;
+    if (ts > t) t = ts;
+    LZ_HIP(temp.alloc(t + 256));
+    cap = (uint32_t)n1;
+    return LZMA_AMD_OK;
+}
+
+int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st) {
+    int rc = reserve(n);
+    if (rc) return rc;
+    const uint32_t mask = lz::bt4_hash_mask(dict_size);
     view.data = d_data;
     view.n = n;
     view.ent4 = ent4.as<MfEnt>();
@@ -250,86 +298,98 @@ int MfWorkspace::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, ui
     view.use8 = fb >= 8;
     if (n == 0) return LZMA_AMD_OK;
 
-    DevBuf kin, kout, vout, grp;  // temporaries sized for the 64-bit keys
-    LZ_HIP(kin.alloc(n1 * 8));
-    LZ_HIP(kout.alloc(n1 * 8));
-    LZ_HIP(vout.alloc(n1 * 4));
-    LZ_HIP(grp.alloc(n1 * 4));
     const unsigned g = grid_for(n, 256);
-    int rc;
     // hash-4 buckets
     hipLaunchKernelGGL((mf_key_kernel<KEY4, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, mask,
                        kin.as<uint32_t>());
-    if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n,
+    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n,
                           bits_of(mask), st)))
         return rc;
     hipLaunchKernelGGL(mf_head_kernel<uint32_t>, dim3(g), dim3(256), 0, st, kout.as<uint32_t>(), n,
                        grp.as<uint32_t>());
-    if ((rc = max_scan(grp.as<uint32_t>(), n, st))) return rc;
+    if ((rc = max_scan(*this, grp.as<uint32_t>(), n, st))) return rc;
     hipLaunchKernelGGL(mf_ent_kernel<4>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
                        grp.as<uint32_t>(), 0u, ent4.as<MfEnt>(), info.as<MfInfo>());
     // 8-gram groups
     if (view.use8) {
         hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            kin.as<uint64_t>());
-        if ((rc = sort_by_key(kin.as<uint64_t>(), kout.as<uint64_t>(), vout.as<uint32_t>(), n, 64, st)))
+        if ((rc = sort_by_key(*this, kin.as<uint64_t>(), kout.as<uint64_t>(), vout.as<uint32_t>(), n, 64,
+                              st)))
             return rc;
         hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, kout.as<uint64_t>(), n,
                            grp.as<uint32_t>());
-        if ((rc = max_scan(grp.as<uint32_t>(), n, st))) return rc;
+        if ((rc = max_scan(*this, grp.as<uint32_t>(), n, st))) return rc;
         hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
                            grp.as<uint32_t>(), 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        kin.as<uint32_t>());
-    if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 16, st)))
+    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 16, st)))
         return rc;
     hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
                        kout.as<uint32_t>(), n, info.as<MfInfo>());
     hipLaunchKernelGGL((mf_key_kernel<KEY2, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        kin.as<uint32_t>());
-    if ((rc = sort_by_key(kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 10, st)))
+    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 10, st)))
         return rc;
     hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
                        kout.as<uint32_t>(), n, info.as<MfInfo>());
     LZ_HIP(hipGetLastError());
-    LZ_HIP(hipStreamSynchronize(st));  // temporaries go out of scope
     return LZMA_AMD_OK;
 }
 
-int MfWorkspace::scan(const uint64_t *d_job_off, uint64_t base, uint64_t j0, uint32_t njobs,
-                      hipStream_t st, uint64_t *total_pairs) {
-    const uint32_t n = view.n;
-    if (total_pairs) *total_pairs = 0;
-    if (n == 0 || njobs == 0) return LZMA_AMD_OK;
+static unsigned scan_blocks(uint32_t n) {
     const uint32_t nruns = (n + kRun - 1) / kRun;
     unsigned blocks = (nruns + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    const uint64_t nwaves = (uint64_t)blocks * 4;
-    LZ_HIP(meta.alloc((size_t)n * 8));
+    return blocks ? blocks : 1;
+}
+
+int MfResult::reserve(uint32_t n) {
+    if (n <= cap && cap != 0) return LZMA_AMD_OK;
+    const size_t n1 = n ? n : 1;
+    LZ_HIP(meta.alloc(n1 * 8));
     LZ_HIP(ctrl.alloc(3 * 8));
-    uint64_t want = (uint64_t)n * 5 + nwaves * kMfPagePairs;
+    const uint64_t want = (uint64_t)n1 * 5 + (uint64_t)scan_blocks((uint32_t)n1) * 4 * kMfPagePairs;
+    LZ_HIP(arena.alloc(want * 8));
+    arena_pairs = want;
+    cap = (uint32_t)n1;
+    return LZMA_AMD_OK;
+}
+
+int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t base, uint64_t j0,
+            uint32_t njobs, hipStream_t st, uint64_t *total_pairs) {
+    const uint32_t n = s.view.n;
+    if (total_pairs) *total_pairs = 0;
+    if (n == 0 || njobs == 0) {
+        LZ_HIP(hipStreamSynchronize(st));
+        return LZMA_AMD_OK;
+    }
+    int rc = r.reserve(n);
+    if (rc) return rc;
+    const unsigned blocks = scan_blocks(n);
+    const uint64_t nwaves = (uint64_t)blocks * 4;
     for (int attempt = 0; attempt < 8; attempt++) {
-        if (arena_pairs < want) {
-            arena.release();
-            LZ_HIP(arena.alloc(want * 8));
-            arena_pairs = want;
-        }
-        LZ_HIP(hipMemsetAsync(ctrl.p, 0, 3 * 8, st));
-        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks), dim3(256), 0, st, view, d_job_off, base, j0,
-                           njobs, meta.as<uint64_t>(), arena.as<uint32_t>(), arena_pairs,
-                           ctrl.as<unsigned long long>());
+        LZ_HIP(hipMemsetAsync(r.ctrl.p, 0, 3 * 8, st));
+        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks), dim3(256), 0, st, s.view, d_job_off, base, j0,
+                           njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
+                           r.ctrl.as<unsigned long long>());
         LZ_HIP(hipGetLastError());
         unsigned long long h[3];
-        LZ_HIP(hipMemcpyAsync(h, ctrl.p, sizeof h, hipMemcpyDeviceToHost, st));
+        LZ_HIP(hipMemcpyAsync(h, r.ctrl.p, sizeof h, hipMemcpyDeviceToHost, st));
         LZ_HIP(hipStreamSynchronize(st));
         if (h[1] == 0) {
             if (total_pairs) *total_pairs = h[2];
             return LZMA_AMD_OK;
         }
-        // the emitted count is exact even when the arena overflowed
-        want = h[2] + h[2] / 16 + nwaves * kMfPagePairs;
+        // the emitted count is exact even when the arena overflowed; growing the arena frees
+        // the old one, which waits for every kernel on the device
+        const uint64_t want = h[2] + h[2] / 16 + nwaves * kMfPagePairs;
+        LZ_HIP(hipDeviceSynchronize());
+        LZ_HIP(r.arena.alloc(want * 8));
+        r.arena_pairs = want;
     }
     return fail(LZMA_AMD_ERR_NOMEM, "match finder arena kept overflowing");
 }
@@ -342,6 +402,7 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
                                         void *stream) {
     hipStream_t st = (hipStream_t)stream;
     lzh::tls().ms_total = lzh::tls().ms_finder = lzh::tls().ms_coder = 0.f;
+    lzh::tls().coder_launches = 0;
     if (dict_size < 1 || fb < 5 || fb > lz::kMatchMax)
         return lzh::fail(LZMA_AMD_ERR_ARG, "bt4_matches: dict_size/fb out of range");
     if (n >= (1ull << 31))
@@ -356,7 +417,8 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     const uint32_t N = (uint32_t)n;
     lzh::Timer t_all, t_scan;
     t_all.start(st);
-    lzh::MfWorkspace ws;
+    lzh::MfScratch ws;
+    lzh::MfResult res;
     int rc = ws.build(d_data, N, dict_size, fb, st);
     if (rc) return rc;
     lzh::DevBuf joff;
@@ -365,11 +427,11 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     LZ_HIP(hipMemcpyAsync(joff.p, h_joff, 16, hipMemcpyHostToDevice, st));
     uint64_t total = 0;
     t_scan.start(st);
-    rc = ws.scan(joff.as<uint64_t>(), 0, 0, 1, st, &total);
+    rc = lzh::mf_scan(ws, res, joff.as<uint64_t>(), 0, 0, 1, st, &total);
     t_scan.stop();
     if (rc) return rc;
     const unsigned g = grid_for(N, 256);
-    hipLaunchKernelGGL(mf_counts_kernel, dim3(g), dim3(256), 0, st, ws.d_meta(), N, d_counts);
+    hipLaunchKernelGGL(mf_counts_kernel, dim3(g), dim3(256), 0, st, res.d_meta(), N, d_counts);
     LZ_HIP(hipMemcpyAsync(d_total_pairs, &total, 8, hipMemcpyHostToDevice, st));
     lzh::DevBuf offs;
     if ((d_pairs && total <= pairs_cap) || d_offsets) {
@@ -385,7 +447,7 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
         LZ_HIP(hipStreamSynchronize(st));
         if (d_offsets) LZ_HIP(hipMemcpyAsync(d_offsets, offs.p, n * 8, hipMemcpyDeviceToDevice, st));
         if (d_pairs && total <= pairs_cap)
-            hipLaunchKernelGGL(mf_gather_kernel, dim3(g), dim3(256), 0, st, ws.d_meta(), ws.d_arena(), N,
+            hipLaunchKernelGGL(mf_gather_kernel, dim3(g), dim3(256), 0, st, res.d_meta(), res.d_arena(), N,
                                offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap);
     }
     t_all.stop();

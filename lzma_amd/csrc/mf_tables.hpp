@@ -1,6 +1,13 @@
 // Host side of the match finder: builds the sorted position tables that
 // lzma_mf_core.hpp scans and runs the scan over a batch of jobs.  Shared by the
 // stand-alone finder entry point and the encoder.
+//
+// Memory is split in two so that batches can be pipelined: MfScratch holds what only
+// the finder itself touches (tables and sort temporaries, reused by every batch) and
+// MfResult what the consumer of a batch reads (one per batch in flight).  Nothing is
+// allocated or freed between reserve() and the end of a call unless an estimate turns
+// out too small: hipFree waits for every kernel on the device, which would serialize
+// a pipeline.
 #pragma once
 #include "host_util.hpp"
 #include "lzma_mf_core.hpp"
@@ -9,22 +16,34 @@ namespace lzh {
 
 constexpr uint32_t kMfPagePairs = 8192;  // arena page: pairs a wave appends to before taking a new page
 
-// Device arrays for one batch of `n` positions (n < 2^32 - 64).
-struct MfWorkspace {
-    DevBuf ent4, ent8, info;  // tables
-    DevBuf meta, arena, ctrl; // results: meta[n] (u64), arena of (len, dist-1) u32 pairs, ctrl words
-    uint64_t arena_pairs = 0;
+struct MfScratch {
+    DevBuf ent4, ent8, info;        // tables (see lzma_mf_core.hpp)
+    DevBuf kin, kout, vout, grp;    // sort keys in/out, sorted positions, group starts
+    DevBuf temp;                    // rocPRIM temporary storage
+    uint32_t cap = 0;               // positions the buffers hold
     lz::MfTables view;
-    // Builds every table for d_data[0..n) on `st` (synchronizes the stream).  dict_size/fb as
+    // Makes room for batches of up to n positions (n < 2^32 - 64).
+    int reserve(uint32_t n);
+    // Builds every table for d_data[0..n) on `st`; no host synchronization.  dict_size/fb as
     // given to the reference's newLzBinTree (lz_bin_tree.go:35).
     int build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st);
-    // Finds the match lists of every position; jobs are [d_job_off[j]-base, d_job_off[j+1]-base)
-    // for j in [j0, j0+njobs).  Results land in meta/arena.  *total_pairs = pairs emitted.
-    // Grows the arena and retries if it was too small (synchronizes the stream).
-    int scan(const uint64_t *d_job_off, uint64_t base, uint64_t j0, uint32_t njobs, hipStream_t st,
-             uint64_t *total_pairs);
+    int need_temp(size_t bytes);
+};
+
+struct MfResult {
+    DevBuf meta, arena, ctrl;  // meta[n] (u64), arena of (len, dist-1) u32 pairs, control words
+    uint64_t arena_pairs = 0;
+    uint32_t cap = 0;
+    int reserve(uint32_t n);
     const uint64_t *d_meta() const { return meta.as<uint64_t>(); }
     const uint32_t *d_arena() const { return arena.as<uint32_t>(); }
 };
+
+// Finds the match lists of every position of the batch whose tables `s` holds; jobs are
+// [d_job_off[j]-base, d_job_off[j+1]-base) for j in [j0, j0+njobs).  Results land in `r`.
+// *total_pairs = pairs emitted.  Synchronizes `st`; grows the arena and retries if it was
+// too small.
+int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t base, uint64_t j0,
+            uint32_t njobs, hipStream_t st, uint64_t *total_pairs);
 
 }  // namespace lzh
