@@ -41,6 +41,18 @@ HBM_PEAK_GBS = 8000.0
 MIB = 1 << 20
 
 
+def pmc_traffic(kernel, input_bytes_per_launch):
+    """HBM bytes per launch of `kernel`, from the committed rocprofv3 PMC summary of this
+    workload (FETCH_SIZE + WRITE_SIZE per input byte, measured in separate counter runs),
+    scaled to this run's launch size.  None if there is no summary."""
+    path = ROOT / "profiles" / "r01_pmc_encode_576x1MiB.json"
+    try:
+        k = json.loads(path.read_text())["kernels"][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    return int(k["hbm_bytes_per_input_byte_reported"] * input_bytes_per_launch)
+
+
 def dist_init(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,7 +156,8 @@ class EncodeWorkload:
         gbs = alg / launches / (avg_ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "encode_kernel", "achieved": round(gbs, 4),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 8),
-                "traffic": None, "kernel_ms": round(avg_ms, 3), "launches_per_step": launches,
+                "traffic": pmc_traffic("encode_kernel", self.n // launches),
+                "kernel_ms": round(avg_ms, 3), "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": alg // launches,
                 "aggregate_achieved": round(alg / (span_ms * 1e-3) / 1e9, 4),
                 "span_ms": round(span_ms, 3),
