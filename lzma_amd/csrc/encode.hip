@@ -68,15 +68,15 @@ struct MfFunctor {
 struct LdsLayout {
     uint32_t probs, prices, pp, opt, small, total;  // byte offsets
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t pb) {
+__host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb) {
     LdsLayout l;
     uint32_t nprobs = lz::kNumBaseProbs;
     l.probs = 0;
     l.prices = (l.probs + nprobs * 2 + 15) & ~15u;
-    l.pp = (l.prices + lz::price_layout(pb).total * 2 + 15) & ~15u;
+    l.pp = (l.prices + lz::price_layout(pb, fb).total * 2 + 15) & ~15u;
     l.opt = l.pp + 512 * 2;
     l.small = l.opt + (lz::kRecWin + lz::kBksWin) * 16;
-    l.total = l.small + lz::kEncSmallWords * 4;
+    l.total = l.small + lz::enc_small_words(fb) * 4;
     return l;
 }
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
                                                     lz::prob_t *lit_scratch, uint64_t lit_stride) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
-    const LdsLayout L = lds_layout(ep.pb);
+    const LdsLayout L = lds_layout(ep.pb, ep.fb);
     LZ_LDS uint8_t *sm = (LZ_LDS uint8_t *)smem;
     LZ_LDS lz::prob_t *probs = (LZ_LDS lz::prob_t *)(sm + L.probs);
     LZ_LDS uint16_t *prices = (LZ_LDS uint16_t *)(sm + L.prices);
@@ -174,8 +174,9 @@ int check_params(const lzma_amd_params *p) {  // checkValues, lzma_encoder.go:11
 }
 
 constexpr uint64_t kMaxChunkBytes = 1ull << 30;  // largest single chunk
-constexpr unsigned kChainsPerCU = 7;              // encode workgroups a CU holds (LDS-limited)
 constexpr unsigned kNumCU = 256;
+constexpr unsigned kLdsPerCU = 160u << 10;
+constexpr unsigned kMaxChainsPerCU = 12;          // three waves per SIMD at the kernel's register count
 constexpr int kEncStreams = 3;                    // encode launches in flight
 
 // Everything one batch in flight owns.
@@ -235,25 +236,30 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     }
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
-    const LdsLayout L = lds_layout(p->pb);
+    const LdsLayout L = lds_layout(p->pb, p->fb);
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
 
-    // resident workgroups on the whole device, fewer if the literal models are large
-    unsigned resident = kNumCU * kChainsPerCU;
+    // resident workgroups on the whole device: as many per CU as LDS and registers allow,
+    // fewer if the literal models are large
+    const unsigned lds_per_wg = (L.total + 1023u) & ~1023u;
+    unsigned resident = kNumCU * std::min(kMaxChainsPerCU, kLdsPerCU / lds_per_wg);
     const uint64_t lit_budget = 2ull << 30;
     if ((uint64_t)resident * lit_stride * sizeof(lz::prob_t) > lit_budget)
         resident = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
 
     // batches: whole chunks, at most batch_bytes each (a larger chunk is a batch of its own)
     const uint64_t total = off[n_chunks] - off[0];
-    uint64_t batch_bytes = 576ull << 20;
+    uint64_t batch_bytes = 768ull << 20;
     int enc_streams = kEncStreams;
     if (const char *e = getenv("LZMA_AMD_BATCH_MIB")) batch_bytes = (uint64_t)atoi(e) << 20;
     if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
+    // with large chunks a batch holds a third of the resident workgroups, so that three
+    // launches fill the device
+    const size_t batch_chunks = n_chunks > resident ? std::max(1u, resident / enc_streams) : resident;
     std::vector<size_t> cut{0};
     for (size_t c = 0; c < n_chunks;) {
         size_t c1 = c + 1;
-        while (c1 < n_chunks && off[c1 + 1] - off[c] <= batch_bytes) c1++;
+        while (c1 < n_chunks && off[c1 + 1] - off[c] <= batch_bytes && c1 - c < batch_chunks) c1++;
         cut.push_back(c1);
         c = c1;
     }
@@ -311,7 +317,10 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
         const uint32_t nchunks = (uint32_t)(c1 - c0);
         t_mf[b].start(S.mf);
-        if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf))) return rc;
+        // the sort temporaries live in the arena the scan is about to fill
+        if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
+                                sl.res.arena.bytes)))
+            return rc;
         uint64_t total_pairs = 0;
         if ((rc = lzh::mf_scan(scratch, sl.res, d_in_off, base, c0, nchunks, S.mf, &total_pairs))) return rc;
         t_mf[b].stop();

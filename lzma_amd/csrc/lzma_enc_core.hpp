@@ -46,15 +46,19 @@ constexpr uint32_t kLanes = 64;
 // follows the parse position `cur`: entries [cur - kRecBack, cur - kRecBack + kRecWin)
 // of the path records and [cur - kBksWin + 1, cur] of the rep-distance records.
 #ifndef LZ_REC_WIN
-#define LZ_REC_WIN 256
+#define LZ_REC_WIN 64
 #endif
 constexpr uint32_t kRecWin = LZ_REC_WIN;           // power of two
 constexpr uint32_t kRecBack = (kRecWin * 3) / 8;   // entries kept behind cur
 constexpr uint32_t kBksWin = kRecWin / 2;          // power of two
-constexpr uint32_t kLaMax = 5 + kMatchMax + 1;  // continuation records: literal, 4 reps, pairs
-constexpr uint32_t kMdistWords = 2 * (kMatchMax + 1) + 2;
+// Sizes that follow from the number of fast bytes: a match list holds at most fb - 1
+// pairs (lengths 2..fb, strictly increasing), and lengths above fb are never priced.
+LZ_HD uint32_t la_max(uint32_t fb) { return 5 + fb + 1; }  // continuation records: literal, 4 reps, pairs
+LZ_HD uint32_t mdist_words(uint32_t fb) { return 2 * (fb + 1) + 2; }
 // uint32 words of caller-provided scratch besides the tables (see Encoder::bind_small)
-constexpr uint32_t kEncSmallWords = 64 + 2 * kPosStatesMax + kNumFullDist + 2 * kLaMax + kMdistWords;
+LZ_HD uint32_t enc_small_words(uint32_t fb) {
+    return 64 + 2 * kPosStatesMax + kNumFullDist + 2 * la_max(fb) + mdist_words(fb);
+}
 
 // LZ_LDS qualifies pointers into LDS, so that their accesses are ds_* instructions
 // and can never be merged with global accesses into flat ones.
@@ -123,13 +127,15 @@ LZ_HD uint32_t pos_slot(uint32_t pos) {
 // Layout of the 16-bit price tables in one array.
 struct PriceLayout {
     uint32_t len, rep_len, pos_slot, dist, align, total;  // offsets in u16 units
+    uint32_t len_stride;                                  // length symbols kept per posState
 };
-LZ_HD PriceLayout price_layout(uint32_t pb) {
+LZ_HD PriceLayout price_layout(uint32_t pb, uint32_t fb) {
     PriceLayout l;
     uint32_t nps = 1u << pb;
+    l.len_stride = (fb + 1 - kMatchMin + 1) & ~1u;  // symbols 0 .. fb - kMatchMin, rounded up to even
     l.len = 0;
-    l.rep_len = l.len + nps * kNumLenSyms;
-    l.pos_slot = l.rep_len + nps * kNumLenSyms;
+    l.rep_len = l.len + nps * l.len_stride;
+    l.pos_slot = l.rep_len + nps * l.len_stride;
     l.dist = l.pos_slot + (kNumLenToPos << kPosSlotBits);
     l.align = l.dist + (kNumLenToPos * kNumFullDist);
     l.total = l.align + kAlignSize;
@@ -191,10 +197,10 @@ struct Encoder {
     U32P xch;                                        // 16 words exchanged between phases
     U32P len_counter;                                // [2][kPosStatesMax]
     U32P temp_prices;                                // kNumFullDist
-    U32P la_tgt, la_price;                           // kLaMax each: target entry (0 = none), price
+    U32P la_tgt, la_price;                           // la_max(fb) each: target entry (0 = none), price
     U32P mdist;                                      // current match list, (len, dist) pairs
 
-    LZ_HD void bind_small(U32P small) {
+    LZ_HD void bind_small(U32P small, uint32_t fb) {
         rep_dist = small;
         reps = small + 4;
         rep_lens = small + 8;
@@ -203,8 +209,8 @@ struct Encoder {
         len_counter = small + 64;
         temp_prices = len_counter + 2 * kPosStatesMax;
         la_tgt = temp_prices + kNumFullDist;
-        la_price = la_tgt + kLaMax;
-        mdist = la_price + kLaMax;
+        la_price = la_tgt + la_max(fb);
+        mdist = la_price + la_max(fb);
     }
 
     // ------------------------------------------------------- optimum table access
@@ -399,7 +405,7 @@ struct Encoder {
         const uint32_t a0 = up0(c0), a1 = up1(c0);
         const uint32_t b0 = a1 + up0(c1);
         const uint32_t b1 = a1 + up1(c1);
-        auto pr = prices + len_tab(which) + ps * kNumLenSyms;
+        auto pr = prices + len_tab(which) + ps * pl.len_stride;
         LZ_PAR_BEGIN(L)
         for (uint32_t i = L; i < nsym; i += kLanes) {
             uint32_t v;
@@ -435,7 +441,7 @@ struct Encoder {
         if (left_ == 0) len_set_prices(which, ps);
     }
     LZ_HD uint32_t len_price(uint32_t which, uint32_t sym, uint32_t ps) const {
-        return prices[len_tab(which) + ps * kNumLenSyms + sym];
+        return prices[len_tab(which) + ps * pl.len_stride + sym];
     }
 
     // ----------------------------------------------------------------- literals
@@ -1248,7 +1254,7 @@ struct Encoder {
     // Models must already hold kProbInit and pp must be built.  Encodes the whole
     // chunk; out_n receives the payload size (header excluded).
     LZ_HD void run(U32P small) {
-        bind_small(small);
+        bind_small(small, ep.fb);
         low = 0;
         out_n = 0;
         cache_size = 1;
@@ -1265,7 +1271,7 @@ struct Encoder {
         for (int i = 0; i < 4; i++) rep_dist[i] = rep_lens[i] = 0;
         pos_state_mask = (1u << ep.pb) - 1;
         lit_pos_mask = (1u << ep.lp) - 1;
-        pl = price_layout(ep.pb);
+        pl = price_layout(ep.pb, ep.fb);
         for (uint32_t ps = 0; ps < (1u << ep.pb); ps++) {
             len_set_prices(0, ps);
             len_set_prices(1, ps);

@@ -19,6 +19,7 @@
 //
 // Roofline class: HBM (N input bytes read, 4N count bytes + 8 bytes per pair
 // written).
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -140,10 +141,9 @@ int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, 
     size_t bytes = 0;
     LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
                                      st));
-    int rc = s.need_temp(bytes);
-    if (rc) return rc;
-    bytes = s.temp.bytes;
-    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp.p, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
+    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
+    bytes = s.temp_bytes;
+    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
                                      st));
     return LZMA_AMD_OK;
 }
@@ -151,10 +151,9 @@ int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, 
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
     size_t bytes = 0;
     LZ_HIP(rocprim::inclusive_scan(nullptr, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
-    int rc = s.need_temp(bytes);
-    if (rc) return rc;
-    bytes = s.temp.bytes;
-    LZ_HIP(rocprim::inclusive_scan(s.temp.p, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
+    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: scan scratch underestimated");
+    bytes = s.temp_bytes;
+    LZ_HIP(rocprim::inclusive_scan(s.temp, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
     return LZMA_AMD_OK;
 }
 
@@ -257,12 +256,20 @@ __global__ __launch_bounds__(256) void mf_counts_kernel(const uint64_t *__restri
 
 namespace lzh {
 
-int MfScratch::need_temp(size_t bytes) {
-    if (bytes <= temp.bytes) return LZMA_AMD_OK;
-    // rare: the estimate made in reserve() was too small (hipFree waits for the device)
-    LZ_HIP(hipDeviceSynchronize());
-    LZ_HIP(temp.alloc(bytes + bytes / 8));
-    return LZMA_AMD_OK;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or scan of n items
+    size_t t = 0;
+    const unsigned bits32[] = {10, 16, 23, 32};
+    for (unsigned b : bits32) t = std::max(t, sort_temp_bytes<uint32_t>(n, b));
+    t = std::max(t, sort_temp_bytes<uint64_t>(n, 64));
+    t = std::max(t, scan_temp_bytes(n));
+    return t + 256;
+}
+
+size_t MfScratch::tmp_bytes(uint32_t n) {
+    const size_t n1 = n ? n : 1;
+    return 2 * align256(n1 * 8) + 2 * align256(n1 * 4) + align256(lib_temp_bytes((uint32_t)n1));
 }
 
 int MfScratch::reserve(uint32_t n) {
@@ -271,22 +278,28 @@ int MfScratch::reserve(uint32_t n) {
     LZ_HIP(ent4.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(ent8.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
-    LZ_HIP(kin.alloc(n1 * 8));  // sized for the 64-bit keys
-    LZ_HIP(kout.alloc(n1 * 8));
-    LZ_HIP(vout.alloc(n1 * 4));
-    LZ_HIP(grp.alloc(n1 * 4));
-    size_t t = sort_temp_bytes<uint64_t>((uint32_t)n1, 64);
-    const size_t t32 = sort_temp_bytes<uint32_t>((uint32_t)n1, 32), ts = scan_temp_bytes((uint32_t)n1);
-    if (t32 > t) t = t32;
-    if (ts > t) t = ts;
-    LZ_HIP(temp.alloc(t + 256));
     cap = (uint32_t)n1;
     return LZMA_AMD_OK;
 }
 
-int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st) {
+int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st,
+                     void *tmp, size_t tmp_cap) {
     int rc = reserve(n);
     if (rc) return rc;
+    {   // lay out the temporaries
+        const size_t n1 = n ? n : 1, need = tmp_bytes(n);
+        if (!tmp || tmp_cap < need) {
+            if (own_tmp.bytes < need) LZ_HIP(own_tmp.alloc(need));
+            tmp = own_tmp.p;
+        }
+        uint8_t *q = (uint8_t *)tmp;
+        kin = q, q += align256(n1 * 8);   // sized for the 64-bit keys
+        kout = q, q += align256(n1 * 8);
+        vout = q, q += align256(n1 * 4);
+        grp = q, q += align256(n1 * 4);
+        temp = q;
+        temp_bytes = need - (size_t)(q - (uint8_t *)tmp);
+    }
     const uint32_t mask = lz::bt4_hash_mask(dict_size);
     view.data = d_data;
     view.n = n;
@@ -301,41 +314,41 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
     const unsigned g = grid_for(n, 256);
     // hash-4 buckets
     hipLaunchKernelGGL((mf_key_kernel<KEY4, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, mask,
-                       kin.as<uint32_t>());
-    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n,
+                       (uint32_t *)kin);
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n,
                           bits_of(mask), st)))
         return rc;
-    hipLaunchKernelGGL(mf_head_kernel<uint32_t>, dim3(g), dim3(256), 0, st, kout.as<uint32_t>(), n,
-                       grp.as<uint32_t>());
-    if ((rc = max_scan(*this, grp.as<uint32_t>(), n, st))) return rc;
-    hipLaunchKernelGGL(mf_ent_kernel<4>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
-                       grp.as<uint32_t>(), 0u, ent4.as<MfEnt>(), info.as<MfInfo>());
+    hipLaunchKernelGGL(mf_head_kernel<uint32_t>, dim3(g), dim3(256), 0, st, (uint32_t *)kout, n,
+                       (uint32_t *)grp);
+    if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
+    hipLaunchKernelGGL(mf_ent_kernel<4>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
+                       (uint32_t *)grp, 0u, ent4.as<MfEnt>(), info.as<MfInfo>());
     // 8-gram groups
     if (view.use8) {
         hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
-                           kin.as<uint64_t>());
-        if ((rc = sort_by_key(*this, kin.as<uint64_t>(), kout.as<uint64_t>(), vout.as<uint32_t>(), n, 64,
+                           (uint64_t *)kin);
+        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)vout, n, 64,
                               st)))
             return rc;
-        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, kout.as<uint64_t>(), n,
-                           grp.as<uint32_t>());
-        if ((rc = max_scan(*this, grp.as<uint32_t>(), n, st))) return rc;
-        hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, vout.as<uint32_t>(),
-                           grp.as<uint32_t>(), 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
+        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (uint64_t *)kout, n,
+                           (uint32_t *)grp);
+        if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
+        hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
+                           (uint32_t *)grp, 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
-                       kin.as<uint32_t>());
-    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 16, st)))
+                       (uint32_t *)kin);
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n, 16, st)))
         return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
-                       kout.as<uint32_t>(), n, info.as<MfInfo>());
+    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, (uint32_t *)vout,
+                       (uint32_t *)kout, n, info.as<MfInfo>());
     hipLaunchKernelGGL((mf_key_kernel<KEY2, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
-                       kin.as<uint32_t>());
-    if ((rc = sort_by_key(*this, kin.as<uint32_t>(), kout.as<uint32_t>(), vout.as<uint32_t>(), n, 10, st)))
+                       (uint32_t *)kin);
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n, 10, st)))
         return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, vout.as<uint32_t>(),
-                       kout.as<uint32_t>(), n, info.as<MfInfo>());
+    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, (uint32_t *)vout,
+                       (uint32_t *)kout, n, info.as<MfInfo>());
     LZ_HIP(hipGetLastError());
     return LZMA_AMD_OK;
 }

@@ -18,16 +18,22 @@ constexpr uint32_t kMfPagePairs = 8192;  // arena page: pairs a wave appends to 
 
 struct MfScratch {
     DevBuf ent4, ent8, info;        // tables (see lzma_mf_core.hpp)
-    DevBuf kin, kout, vout, grp;    // sort keys in/out, sorted positions, group starts
-    DevBuf temp;                    // rocPRIM temporary storage
-    uint32_t cap = 0;               // positions the buffers hold
+    DevBuf own_tmp;                 // temporaries, when the caller lends no memory for them
+    uint32_t cap = 0;               // positions the tables hold
     lz::MfTables view;
-    // Makes room for batches of up to n positions (n < 2^32 - 64).
+    // temporaries of one build: sort keys in/out, sorted positions, group starts, library scratch
+    void *kin = nullptr, *kout = nullptr, *vout = nullptr, *grp = nullptr, *temp = nullptr;
+    size_t temp_bytes = 0;
+    // Makes room for the tables of batches of up to n positions (n < 2^32 - 64).
     int reserve(uint32_t n);
+    // Bytes of temporaries a build of n positions needs.
+    static size_t tmp_bytes(uint32_t n);
     // Builds every table for d_data[0..n) on `st`; no host synchronization.  dict_size/fb as
-    // given to the reference's newLzBinTree (lz_bin_tree.go:35).
-    int build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st);
-    int need_temp(size_t bytes);
+    // given to the reference's newLzBinTree (lz_bin_tree.go:35).  The temporaries go to
+    // tmp[0..tmp_cap) if that is large enough (memory that is dead until the scan, such as the
+    // arena the scan will fill), else to an allocation of their own.
+    int build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st,
+              void *tmp = nullptr, size_t tmp_cap = 0);
 };
 
 struct MfResult {

@@ -98,11 +98,11 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     cm.build();
     lz::EncParams ep = {fb, lc, lp, pb, 1u << dict_log, dict_log * 2, (uint32_t)(eos != 0)};
     std::vector<lz::prob_t> probs(lz::kNumBaseProbs + ((size_t)0x300 << (lc + lp)), lz::kProbInit);
-    std::vector<uint16_t> prices(lz::price_layout(pb).total, 0), pp(512);
+    std::vector<uint16_t> prices(lz::price_layout(pb, fb).total, 0), pp(512);
     std::vector<lz::OptG> opt_g(lz::kNumOpts);
     std::vector<lz::Rec> opt_rec(lz::kRecWin);
     std::vector<lz::Reps> opt_bks(lz::kBksWin);
-    std::vector<uint32_t> small(lz::kEncSmallWords);
+    std::vector<uint32_t> small(lz::enc_small_words(fb));
     lz::build_prob_prices(pp.data(), 0, 1);
     lz::Encoder<ChainMFRef, lz::prob_t *> e;
     e.data = padded.data();
