@@ -15,16 +15,19 @@
 // at a time, one per lane, record breakers picked with a ballot.
 //
 // To avoid scanning whole buckets (about 1400 candidates per position on text),
-// positions are also grouped by their exact first 8 bytes.  All candidates sharing
-// at least 8 bytes with P are in P's 8-gram group; every bucket member newer than
-// the newest of them (Q*) shares fewer than 8.  So the bucket is scanned only down
-// to Q*, and from Q* on the (much shorter) 8-gram group is scanned instead.
+// positions are also grouped by their exact first 8 and first 16 bytes.  All candidates
+// sharing at least 8 bytes with P are in P's 8-gram group; every bucket member newer
+// than the newest of them (Q8) shares fewer than 8.  So the bucket is scanned only down
+// to Q8; from Q8 on the (much shorter) 8-gram group is scanned instead, and that one
+// only down to the newest position sharing 16 bytes (Q16), from where the 16-gram
+// group takes over.
 //
-// Both scans stream: the sorted tables carry, next to each position, the bytes
-// needed to compare it (first 8 bytes in the bucket table, bytes 8..15 in the
-// 8-gram table), so the lanes read consecutive 16-byte entries instead of
-// gathering from the window; only common prefixes of 16 bytes or more touch the
-// window itself.
+// All three scans stream: the sorted tables carry, next to each position, the bytes
+// needed to compare it (bytes 0..7 in the bucket table, 8..15 in the 8-gram table,
+// 16..23 in the 16-gram table), so the lanes read consecutive 12-byte entries instead
+// of gathering from the window; only common prefixes of 24 bytes or more touch the
+// window itself.  Most scans end within a few candidates, so the first step of each
+// reads 16 entries and only the following ones 64.
 #pragma once
 #include "lzma_common.hpp"
 
@@ -32,16 +35,16 @@ namespace lz {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-// One entry of a sorted table: a position, the index of the first entry of its
-// bucket/group, and 8 bytes of its text (see above).
-struct __attribute__((aligned(16))) MfEnt {
-    uint32_t pos, gstart;
-    uint64_t sig;
+// One entry of a sorted table: a position and 8 bytes of its text (see above).
+struct MfEnt {
+    uint32_t pos, sig_lo, sig_hi;
 };
-// Per position: its index in both tables and the previous position with the same
-// hash-2 / hash-3 slot (kNone if there is none).
+// Per position: its index in the three tables with the index of the first entry of
+// its bucket / group in each, and the previous position with the same hash-2 / hash-3
+// slot (kNone if there is none).
 struct __attribute__((aligned(16))) MfInfo {
-    uint32_t rank4, rank8, prev2, prev3;
+    uint32_t rank4, g4, rank8, g8;
+    uint32_t rank16, g16, prev2, prev3;
 };
 
 struct MfTables {
@@ -49,8 +52,9 @@ struct MfTables {
     uint32_t n;           // bytes in data
     const MfEnt *ent4;    // (hash-4 slot, position) order, sig = bytes 0..7
     const MfEnt *ent8;    // (bytes 0..7, position) order, sig = bytes 8..15
+    const MfEnt *ent16;   // (bytes 0..15, position) order, sig = bytes 16..23
     const MfInfo *info;
-    uint32_t dict, fb, use8;
+    uint32_t dict, fb, use8, use16;
 };
 
 // Result word per position: pair offset in the arena (upper 48 bits) and count.
@@ -90,18 +94,62 @@ LZ_D uint32_t mf_extend(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q,
 LZ_D uint32_t mf_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 LZ_D uint64_t mf_u64(uint64_t v) { return ((uint64_t)mf_u32((uint32_t)(v >> 32)) << 32) | mf_u32((uint32_t)v); }
 
-// Match list of position P of the job [job_start, job_end).  Called by all 64 lanes
-// of a wave with identical arguments (inf = t.info[P], fetched by the caller ahead of
-// time); emit(k, length, distance-1) is called once per pair, k = 0, 1, ... (identically
-// on every lane); returns the number of pairs.  A later emit with a smaller k overwrites
-// (the reference drops seed pairs that way).
-//
-// Everything that can be addressed from inf -- P's own two table entries, the 64
-// newest entries of its bucket and of its 8-gram group, the two seed bytes -- is
-// requested in one batch, so a typical position costs one memory round trip.
+// One level of the scan: entries tab[top-1], tab[top-2], ... down to tab[bottom], newest
+// first, as long as their position is >= low.  `first` holds the 16 newest (lane k: entry
+// top-1-k), fetched by the caller.  Candidate lengths are `known` + the bytes sig shares
+// with psig, continued in the window beyond known+8 if `deep`.  Record breakers are
+// emitted in order.  Returns true if a match of len_limit ended the whole search.
 template <class Emit>
-LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, const MfInfo &inf, uint32_t job_start,
-                      uint32_t job_end, Emit emit, uint32_t lane) {
+LZ_D bool mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t bottom, const MfEnt &first,
+                   uint32_t low, uint64_t psig, uint32_t known, bool deep, uint32_t P, uint32_t len_limit,
+                   uint32_t &n, uint32_t &max_len, Emit &emit, uint32_t lane) {
+    const uint32_t count = top - bottom;  // entries older than P in the group
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t w = done == 0 ? 16u : 64u;
+        bool valid = lane < w && done + lane < count;
+        uint32_t Q = 0, l = 0;
+        if (valid) {
+            MfEnt e = first;
+            if (done != 0) e = tab[top - 1 - done - lane];
+            Q = e.pos;
+            valid = Q >= low;
+            const uint64_t x = (((uint64_t)e.sig_hi << 32) | e.sig_lo) ^ psig;
+            l = known + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8);
+            if (deep && valid && x == 0 && len_limit > known + 8)
+                l = mf_extend(t.data, t.n, P, Q, known + 8, len_limit);
+            if (l > len_limit) l = len_limit;
+        }
+        for (;;) {  // record breakers in lane order
+            const unsigned long long m = __ballot(valid && l > max_len);
+            if (m == 0) break;
+            const int f = __builtin_ctzll(m);
+            const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
+            const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)Q, f);
+            emit(n, bl, P - bq - 1);
+            n++;
+            max_len = bl;
+            if (bl == len_limit) return true;  // lz_bin_tree.go:231-235
+        }
+        // go on only if every entry of this step was a candidate
+        if (__ballot(valid) != (w == 16 ? 0xFFFFull : ~0ull)) break;
+        done += w;
+    }
+    return false;
+}
+
+// Match list of position P of the job [job_start, job_end).  Called by all 64 lanes
+// of a wave with identical arguments (inf = t.info[P] and p0/p8/p16 = bytes 0..7, 8..15,
+// 16..23 at P, fetched by the caller ahead of time); emit(k, length, distance-1) is
+// called once per pair, k = 0, 1, ... (identically on every lane); returns the number
+// of pairs.  A later emit with a smaller k overwrites (the reference drops seed pairs
+// that way).
+//
+// Everything that can be addressed from inf -- the 16 newest entries of the bucket, of
+// the 8-gram group and of the 16-gram group, the two seed bytes -- is requested in one
+// batch, so a typical position costs one memory round trip.
+template <class Emit>
+LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_t p0, uint64_t p8,
+                      uint64_t p16, uint32_t job_start, uint32_t job_end, Emit emit, uint32_t lane) {
     const uint32_t left = job_end - P;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
     if (len_limit < 4) return 0;  // lz_bin_tree.go:121-124
@@ -110,28 +158,27 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, const MfInfo &inf, uint32_t
     uint32_t W = P > t.dict ? P - t.dict : 0;
     if (W < job_start) W = job_start;
     const bool use8 = t.use8 && len_limit >= 8;
+    const bool use16 = use8 && t.use16 && len_limit >= 16;
 
     // ---- one batch of loads
-    const uint32_t r4 = inf.rank4, r8 = inf.rank8, q2 = inf.prev2, q3 = inf.prev3;
-    const MfEnt me4_v = t.ent4[r4];
-    MfEnt me8_v = me4_v, a0, b0;
-    a0.pos = 0, a0.gstart = 0, a0.sig = 0;
-    b0 = a0;
-    if (use8) me8_v = t.ent8[r8];
-    if (r4 > lane) a0 = t.ent4[r4 - 1 - lane];
-    if (use8 && r8 > lane) b0 = t.ent8[r8 - 1 - lane];
+    const uint32_t r4 = inf.rank4, g4 = inf.g4, r8 = inf.rank8, g8 = inf.g8, r16 = inf.rank16, g16 = inf.g16;
+    const uint32_t q2 = inf.prev2, q3 = inf.prev3;
+    MfEnt a0, b0, c0;
+    a0.pos = 0, a0.sig_lo = 0, a0.sig_hi = 0;
+    b0 = a0, c0 = a0;
+    if (lane < 16 && lane < r4 - g4) a0 = t.ent4[r4 - 1 - lane];
+    if (use8 && lane < 16 && lane < r8 - g8) b0 = t.ent8[r8 - 1 - lane];
+    if (use16 && lane < 16 && lane < r16 - g16) c0 = t.ent16[r16 - 1 - lane];
     uint32_t b2_v = 0x100, b3_v = 0x100;
     if (q2 != kNone && q2 >= W) b2_v = data[q2];
     if (q3 != kNone && q3 >= W) b3_v = data[q3];
 
-    const uint32_t g4 = mf_u32(me4_v.gstart);
-    const uint64_t p8 = mf_u64(me4_v.sig);  // P's first 8 bytes
     uint32_t q4 = kNone;
     if (r4 > g4) {
         q4 = (uint32_t)__builtin_amdgcn_readlane((int)a0.pos, 0);
         if (q4 < job_start) q4 = kNone;
     }
-    const uint32_t b0byte = (uint32_t)p8 & 0xFF;
+    const uint32_t b0byte = (uint32_t)p0 & 0xFF;
     const uint32_t b2 = mf_u32(b2_v), b3 = mf_u32(b3_v);
     uint32_t n = 0, max_len = 1, last = q2;
     // seeds, lz_bin_tree.go:154-180
@@ -152,75 +199,26 @@ LZ_D uint32_t mf_find(const MfTables &t, uint32_t P, const MfInfo &inf, uint32_t
         max_len = 1;
     }
 
-    // newest position sharing P's first 8 bytes
-    uint32_t qstar = kNone, g8 = 0;
-    uint64_t pn8 = 0;
-    if (use8) {
-        g8 = mf_u32(me8_v.gstart);
-        pn8 = mf_u64(me8_v.sig);  // P's bytes 8..15
-        if (r8 > g8) {
-            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)b0.pos, 0);
-            if (q >= W) qstar = q;
-        }
+    // newest positions sharing P's first 8 and first 16 bytes
+    uint32_t q8s = kNone, q16s = kNone;
+    if (use8 && r8 > g8) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)b0.pos, 0);
+        if (q >= W) q8s = q;
     }
-    const uint32_t low_a = qstar != kNone ? qstar + 1 : W;
-
-    // ---- scan of the hash-4 bucket, newest first, down to low_a
-    for (uint32_t base = r4; base > g4; base -= 64) {
-        bool valid = base > g4 + lane;  // index base-1-lane is still inside the bucket
-        uint32_t Q = 0, l = 0;
-        if (valid) {
-            MfEnt e = a0;
-            if (base != r4) e = t.ent4[base - 1 - lane];
-            Q = e.pos;
-            valid = Q >= low_a;
-            const uint64_t x = e.sig ^ p8;
-            l = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
-            if (l >= 8 && len_limit > 8) l = mf_extend(data, t.n, P, Q, 8, len_limit);  // only if !use8
-            if (l > len_limit) l = len_limit;
-        }
-        for (;;) {  // record breakers in lane order
-            unsigned long long m = __ballot(valid && l > max_len);
-            if (m == 0) break;
-            const int f = __builtin_ctzll(m);
-            const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
-            const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)Q, f);
-            emit(n, bl, P - bq - 1);
-            n++;
-            max_len = bl;
-            if (bl == len_limit) return n;  // lz_bin_tree.go:231-235
-        }
-        if (__ballot(valid) != ~0ull || base - g4 <= 64) break;
+    if (use16 && r16 > g16) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)c0.pos, 0);
+        if (q >= W) q16s = q;
     }
-    if (qstar == kNone) return n;
-
-    // ---- scan of the 8-gram group from Q* on
-    for (uint32_t base = r8; base > g8; base -= 64) {
-        bool valid = base > g8 + lane;
-        uint32_t Q = 0, l = 0;
-        if (valid) {
-            MfEnt e = b0;
-            if (base != r8) e = t.ent8[base - 1 - lane];
-            Q = e.pos;
-            valid = Q >= W;
-            const uint64_t y = e.sig ^ pn8;
-            l = 8 + (y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8);
-            if (valid && l >= 16 && len_limit > 16) l = mf_extend(data, t.n, P, Q, 16, len_limit);
-            if (l > len_limit) l = len_limit;
-        }
-        for (;;) {
-            unsigned long long m = __ballot(valid && l > max_len);
-            if (m == 0) break;
-            const int f = __builtin_ctzll(m);
-            const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
-            const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)Q, f);
-            emit(n, bl, P - bq - 1);
-            n++;
-            max_len = bl;
-            if (bl == len_limit) return n;
-        }
-        if (__ballot(valid) != ~0ull || base - g8 <= 64) break;
-    }
+    // the hash-4 bucket down to Q8, the 8-gram group down to Q16, the 16-gram group
+    if (mf_level(t, t.ent4, r4, g4, a0, q8s != kNone ? q8s + 1 : W, p0, 0, false, P, len_limit, n, max_len, emit,
+                 lane))
+        return n;
+    if (q8s == kNone) return n;
+    if (mf_level(t, t.ent8, r8, g8, b0, q16s != kNone ? q16s + 1 : W, p8, 8, false, P, len_limit, n, max_len,
+                 emit, lane))
+        return n;
+    if (q16s == kNone) return n;
+    mf_level(t, t.ent16, r16, g16, c0, W, p16, 16, true, P, len_limit, n, max_len, emit, lane);
     return n;
 }
 

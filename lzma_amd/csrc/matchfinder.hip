@@ -6,11 +6,12 @@
 //      first 8 bytes of every position;
 //   2. stable radix sorts of (key, position) -- rocPRIM device radix sort, the one
 //      library primitive used -- giving each bucket's positions in ascending order;
-//   3. table kernels: 16-byte entries (position, start of its bucket, 8 bytes of its
-//      text) in sorted order, and per position its rank in both tables and the
-//      previous position with the same hash-2 / hash-3 slot;
+//   3. table kernels: 12-byte entries (position, 8 bytes of its text) in sorted order
+//      for the hash-4 buckets, the 8-gram groups and the 16-gram groups, and per
+//      position its rank and its group's start in each table and the previous
+//      position with the same hash-2 / hash-3 slot;
 //   4. the scan kernel (lzma_mf_core.hpp): one wave per position, 64 candidates per
-//      step read as consecutive 16-byte entries, record breakers by ballot.  Each
+//      step read as consecutive 12-byte entries, record breakers by ballot.  Each
 //      wave walks a run of consecutive positions and appends their pairs to a
 //      private page of a global arena (one atomic per 8192 pairs); a word per
 //      position records where its pairs are.
@@ -36,6 +37,7 @@ using lz::MfInfo;
 
 enum { KEY2 = 2, KEY3 = 3, KEY4 = 4, KEY8 = 8 };
 
+// KEY8: mask is the byte offset of the 8 bytes taken as the key
 template <int KIND, class K>
 __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      uint32_t mask, K *__restrict__ keys) {
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__
     __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t w = lz::mf_load8(data, n, i);
+        const uint64_t w = lz::mf_load8(data, n, KIND == KEY8 ? i + mask : i);
         if (KIND == KEY8) {
             keys[i] = (K)w;
         } else {
@@ -73,7 +75,29 @@ __global__ __launch_bounds__(256) void mf_head_kernel(const K *__restrict__ skey
         head[j] = (j > 0 && skey[j - 1] != skey[j]) ? j : 0;
 }
 
-// ent[j] = {ord[j], gstart[j], 8 bytes at data[ord[j] + sig_off]};  rank of ord[j] = j
+// 16-gram groups: skey holds bytes 0..7 of the sorted positions, bytes 8..15 come from the text
+__global__ __launch_bounds__(256) void mf_head16_kernel(const uint8_t *__restrict__ data, uint32_t n,
+                                                        const uint64_t *__restrict__ skey,
+                                                        const uint32_t *__restrict__ ord,
+                                                        uint32_t *__restrict__ head) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        bool same = j > 0 && skey[j - 1] == skey[j];
+        if (same) same = lz::mf_load8(data, n, ord[j - 1] + 8) == lz::mf_load8(data, n, ord[j] + 8);
+        head[j] = same ? 0 : j;
+    }
+}
+
+// keys[j] = bytes 0..7 of position ord[j]
+__global__ __launch_bounds__(256) void mf_gather_key_kernel(const uint8_t *__restrict__ data, uint32_t n,
+                                                            const uint32_t *__restrict__ ord,
+                                                            uint64_t *__restrict__ keys) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+        keys[j] = lz::mf_load8(data, n, ord[j]);
+}
+
+// ent[j] = {ord[j], 8 bytes at data[ord[j] + sig_off]};  rank of ord[j] = j, its group starts at gstart[j]
 template <int WHICH>
 __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      const uint32_t *__restrict__ ord,
@@ -83,12 +107,15 @@ __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t p = ord[j];
+        const uint64_t sig = lz::mf_load8(data, n, p + sig_off);
         MfEnt e;
         e.pos = p;
-        e.gstart = gstart[j];
-        e.sig = lz::mf_load8(data, n, p + sig_off);
+        e.sig_lo = (uint32_t)sig, e.sig_hi = (uint32_t)(sig >> 32);
         ent[j] = e;
-        if (WHICH == 4) info[p].rank4 = j; else info[p].rank8 = j;
+        const uint32_t g = gstart[j];
+        if (WHICH == 4) info[p].rank4 = j, info[p].g4 = g;
+        else if (WHICH == 8) info[p].rank8 = j, info[p].g8 = g;
+        else info[p].rank16 = j, info[p].g16 = g;
     }
 }
 
@@ -148,6 +175,17 @@ int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, 
     return LZMA_AMD_OK;
 }
 
+// same with the values given (stable: equal keys keep the order of vals_in)
+int sort_values_by_key(lzh::MfScratch &s, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in,
+                       uint32_t *vals_out, uint32_t n, hipStream_t st) {
+    size_t bytes = 0;
+    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
+    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
+    bytes = s.temp_bytes;
+    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
+    return LZMA_AMD_OK;
+}
+
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
     size_t bytes = 0;
     LZ_HIP(rocprim::inclusive_scan(nullptr, bytes, io, io, n, rocprim::maximum<uint32_t>(), st));
@@ -190,11 +228,23 @@ __global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint
         uint32_t job = lo;
         uint32_t js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
         lz::MfInfo inf_next = t.info[p_begin];
+        // bytes 0..23 at P, rolled along by one byte per position
+        uint64_t w0 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin)), w1 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin + 8)),
+                 w2 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin + 16));
+        uint32_t byte_next = p_begin + 24 < n ? t.data[p_begin + 24] : 0;
         for (uint32_t P = p_begin; P < p_end; P++) {
             lz::MfInfo inf = inf_next;
-            inf.rank4 = lz::mf_u32(inf.rank4), inf.rank8 = lz::mf_u32(inf.rank8);
+            inf.rank4 = lz::mf_u32(inf.rank4), inf.g4 = lz::mf_u32(inf.g4);
+            inf.rank8 = lz::mf_u32(inf.rank8), inf.g8 = lz::mf_u32(inf.g8);
+            inf.rank16 = lz::mf_u32(inf.rank16), inf.g16 = lz::mf_u32(inf.g16);
             inf.prev2 = lz::mf_u32(inf.prev2), inf.prev3 = lz::mf_u32(inf.prev3);
-            if (P + 1 < p_end) inf_next = t.info[P + 1];
+            const uint64_t p0 = w0, p8 = w1, p16 = w2;
+            const uint32_t bn = lz::mf_u32(byte_next);
+            if (P + 1 < p_end) {
+                inf_next = t.info[P + 1];
+                byte_next = P + 25 < n ? t.data[P + 25] : 0;
+            }
+            w0 = (w0 >> 8) | (w1 << 56), w1 = (w1 >> 8) | (w2 << 56), w2 = (w2 >> 8) | ((uint64_t)bn << 56);
             while (P >= je) {  // empty jobs are skipped
                 job++;
                 js = je;
@@ -219,7 +269,7 @@ __global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint
                     dst[2 * k + 1] = dist;
                 }
             };
-            const uint32_t c = lz::mf_find(t, P, inf, js, je, emit, lane);
+            const uint32_t c = lz::mf_find(t, P, inf, p0, p8, p16, js, je, emit, lane);
             if (lane == 0) meta[P] = lz::mf_meta(cursor, c);
             if (!overflow) cursor += c;
             emitted += c;
@@ -263,6 +313,13 @@ static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or sc
     const unsigned bits32[] = {10, 16, 23, 32};
     for (unsigned b : bits32) t = std::max(t, sort_temp_bytes<uint32_t>(n, b));
     t = std::max(t, sort_temp_bytes<uint64_t>(n, 64));
+    {
+        size_t b = 0;
+        (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                 (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64,
+                                                 (hipStream_t) nullptr);
+        t = std::max(t, b);
+    }
     t = std::max(t, scan_temp_bytes(n));
     return t + 256;
 }
@@ -277,6 +334,7 @@ int MfScratch::reserve(uint32_t n) {
     const size_t n1 = n ? n : 1;
     LZ_HIP(ent4.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(ent8.alloc(n1 * sizeof(MfEnt)));
+    LZ_HIP(ent16.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
     cap = (uint32_t)n1;
     return LZMA_AMD_OK;
@@ -305,10 +363,12 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
     view.n = n;
     view.ent4 = ent4.as<MfEnt>();
     view.ent8 = ent8.as<MfEnt>();
+    view.ent16 = ent16.as<MfEnt>();
     view.info = info.as<MfInfo>();
     view.dict = dict_size;
     view.fb = fb;
     view.use8 = fb >= 8;
+    view.use16 = fb >= 16;
     if (n == 0) return LZMA_AMD_OK;
 
     const unsigned g = grid_for(n, 256);
@@ -335,6 +395,23 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
         if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
         hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
                            (uint32_t *)grp, 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
+    }
+    // 16-gram groups: order by bytes 8..15 first, then (stable) by bytes 0..7
+    if (view.use16) {
+        hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 8u,
+                           (uint64_t *)kin);
+        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)grp, n, 64, st)))
+            return rc;
+        hipLaunchKernelGGL(mf_gather_key_kernel, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)grp,
+                           (uint64_t *)kin);
+        if ((rc = sort_values_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)grp,
+                                     (uint32_t *)vout, n, st)))
+            return rc;
+        hipLaunchKernelGGL(mf_head16_kernel, dim3(g), dim3(256), 0, st, d_data, n, (uint64_t *)kout,
+                           (uint32_t *)vout, (uint32_t *)grp);
+        if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
+        hipLaunchKernelGGL(mf_ent_kernel<16>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
+                           (uint32_t *)grp, 16u, ent16.as<MfEnt>(), info.as<MfInfo>());
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,

@@ -17,7 +17,7 @@ namespace lzh {
 constexpr uint32_t kMfPagePairs = 8192;  // arena page: pairs a wave appends to before taking a new page
 
 struct MfScratch {
-    DevBuf ent4, ent8, info;        // tables (see lzma_mf_core.hpp)
+    DevBuf ent4, ent8, ent16, info; // tables (see lzma_mf_core.hpp)
     DevBuf own_tmp;                 // temporaries, when the caller lends no memory for them
     uint32_t cap = 0;               // positions the tables hold
     lz::MfTables view;
