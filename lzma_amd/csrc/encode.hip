@@ -239,10 +239,18 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     const LdsLayout L = lds_layout(p->pb, p->fb);
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
 
-    // resident workgroups on the whole device: as many per CU as LDS and registers allow,
-    // fewer if the literal models are large
-    const unsigned lds_per_wg = (L.total + 1023u) & ~1023u;
-    unsigned resident = kNumCU * std::min(kMaxChainsPerCU, kLdsPerCU / lds_per_wg);
+    // resident workgroups on the whole device: as many per CU as LDS and registers allow
+    // (LDS is handed out in 1280-byte units; measured), fewer if the literal models are large.
+    // A grid larger than what is really resident would leave workgroups waiting for a whole
+    // chunk's time, so the estimate is the minimum of the runtime's and our own.
+    const unsigned lds_per_wg = (L.total + 1279u) / 1280u * 1280u;
+    unsigned per_cu = std::min(kMaxChainsPerCU, kLdsPerCU / lds_per_wg);
+    {
+        int api = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel, 64, L.total) == hipSuccess && api > 0)
+            per_cu = std::min(per_cu, (unsigned)api);
+    }
+    unsigned resident = kNumCU * std::max(1u, per_cu);
     const uint64_t lit_budget = 2ull << 30;
     if ((uint64_t)resident * lit_stride * sizeof(lz::prob_t) > lit_budget)
         resident = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));

@@ -57,7 +57,7 @@ LZ_HD uint32_t la_max(uint32_t fb) { return 5 + fb + 1; }  // continuation recor
 LZ_HD uint32_t mdist_words(uint32_t fb) { return 2 * (fb + 1) + 2; }
 // uint32 words of caller-provided scratch besides the tables (see Encoder::bind_small)
 LZ_HD uint32_t enc_small_words(uint32_t fb) {
-    return 64 + 2 * kPosStatesMax + kNumFullDist + 2 * la_max(fb) + mdist_words(fb);
+    return 32 + 2 * kPosStatesMax + kNumFullDist + 2 * la_max(fb) + mdist_words(fb);
 }
 
 // LZ_LDS qualifies pointers into LDS, so that their accesses are ds_* instructions
@@ -206,7 +206,7 @@ struct Encoder {
         rep_lens = small + 8;
         rep_prp = small + 12;
         xch = small + 16;
-        len_counter = small + 64;
+        len_counter = small + 32;
         temp_prices = len_counter + 2 * kPosStatesMax;
         la_tgt = temp_prices + kNumFullDist;
         la_price = la_tgt + la_max(fb);

@@ -201,81 +201,95 @@ unsigned bits_of(uint32_t mask) {
     return b ? b : 1;
 }
 
-constexpr uint32_t kRun = 256;  // consecutive positions handled by one wave before it moves on
+constexpr uint32_t kRun = 256;     // consecutive positions handled by one wave before it moves on
+constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quarter
 
 // ctrl[0] = next free arena pair index, ctrl[1] = overflow flag, ctrl[2] = pairs emitted
+//
+// Each row of a wave walks its own run of consecutive positions and appends their pairs to
+// a private page of the arena (one atomic per page); the result word of a position says
+// where its pairs are.
 __global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
                                                       unsigned long long *ctrl) {
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, idx = lane & 15, row = lane >> 4, row_base = lane & 48;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const uint32_t n = t.n;
     const uint32_t nruns = (n + kRun - 1) / kRun;
-    uint64_t cursor = 0, page_end = 0;  // wave-private arena page
+    uint64_t cursor = 0, page_end = 0;  // the row's arena page
     uint64_t emitted = 0;
     bool overflow = false;
     for (uint32_t run = wave; run < nruns; run += nwaves) {
-        const uint32_t p_begin = run * kRun;
-        const uint32_t p_end = p_begin + kRun < n ? p_begin + kRun : n;
+        const uint32_t p_begin = run * kRun + row * kRowRun;
+        uint32_t p_end = p_begin + kRowRun;
+        if (p_end > n) p_end = n;
+        const bool row_on = p_begin < n;
         // job containing p_begin: last j with job_off[j] - base <= p_begin
-        uint32_t lo = 0, hi = njobs;  // invariant: off[lo] <= p_begin < off[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (job_off[j0 + mid] - base <= p_begin) lo = mid; else hi = mid;
+        uint32_t job = 0, js = 0, je = 0;
+        lz::MfInfo inf_next = {};
+        uint64_t w0 = 0, w1 = 0, w2 = 0;  // bytes 0..23 at P, rolled along by one byte per position
+        uint32_t byte_next = 0;
+        if (row_on) {
+            uint32_t lo = 0, hi = njobs;  // invariant: off[lo] <= p_begin < off[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (job_off[j0 + mid] - base <= p_begin) lo = mid; else hi = mid;
+            }
+            job = lo;
+            js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
+            inf_next = t.info[p_begin];
+            w0 = lz::mf_load8(t.data, n, p_begin), w1 = lz::mf_load8(t.data, n, p_begin + 8);
+            w2 = lz::mf_load8(t.data, n, p_begin + 16);
+            byte_next = p_begin + 24 < n ? t.data[p_begin + 24] : 0;
         }
-        uint32_t job = lo;
-        uint32_t js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
-        lz::MfInfo inf_next = t.info[p_begin];
-        // bytes 0..23 at P, rolled along by one byte per position
-        uint64_t w0 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin)), w1 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin + 8)),
-                 w2 = lz::mf_u64(lz::mf_load8(t.data, n, p_begin + 16));
-        uint32_t byte_next = p_begin + 24 < n ? t.data[p_begin + 24] : 0;
-        for (uint32_t P = p_begin; P < p_end; P++) {
-            lz::MfInfo inf = inf_next;
-            inf.rank4 = lz::mf_u32(inf.rank4), inf.g4 = lz::mf_u32(inf.g4);
-            inf.rank8 = lz::mf_u32(inf.rank8), inf.g8 = lz::mf_u32(inf.g8);
-            inf.rank16 = lz::mf_u32(inf.rank16), inf.g16 = lz::mf_u32(inf.g16);
-            inf.prev2 = lz::mf_u32(inf.prev2), inf.prev3 = lz::mf_u32(inf.prev3);
+        for (uint32_t k = 0; k < kRowRun; k++) {
+            const uint32_t P = p_begin + k;
+            const bool act = row_on && P < p_end;
+            if (!__any(act)) break;
+            const lz::MfInfo inf = inf_next;
             const uint64_t p0 = w0, p8 = w1, p16 = w2;
-            const uint32_t bn = lz::mf_u32(byte_next);
-            if (P + 1 < p_end) {
+            const uint32_t bn = byte_next;
+            if (act && P + 1 < p_end) {
                 inf_next = t.info[P + 1];
                 byte_next = P + 25 < n ? t.data[P + 25] : 0;
             }
             w0 = (w0 >> 8) | (w1 << 56), w1 = (w1 >> 8) | (w2 << 56), w2 = (w2 >> 8) | ((uint64_t)bn << 56);
-            while (P >= je) {  // empty jobs are skipped
-                job++;
-                js = je;
-                je = (uint32_t)(job_off[j0 + job + 1] - base);
-            }
-            if (page_end - cursor < lz::kMatchMax + 1 && !overflow) {
+            if (act)
+                while (P >= je) {  // empty jobs are skipped
+                    job++;
+                    js = je;
+                    je = (uint32_t)(job_off[j0 + job + 1] - base);
+                }
+            // a fresh page if this one cannot take a full list
+            const bool need = act && !overflow && page_end - cursor < lz::kMatchMax + 1;
+            if (__any(need)) {
                 unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&ctrl[0], (unsigned long long)lzh::kMfPagePairs);
-                b = __shfl(b, 0);
-                if (b + lzh::kMfPagePairs > arena_pairs) {
-                    overflow = true;
-                } else {
-                    cursor = b;
-                    page_end = b + lzh::kMfPagePairs;
+                if (need && idx == 0) b = atomicAdd(&ctrl[0], (unsigned long long)lzh::kMfPagePairs);
+                const uint32_t b_lo = lz::row_first((uint32_t)b, row_base), b_hi = lz::row_first((uint32_t)(b >> 32), row_base);
+                b = ((unsigned long long)b_hi << 32) | b_lo;
+                if (need) {
+                    if (b + lzh::kMfPagePairs > arena_pairs) {
+                        overflow = true;
+                    } else {
+                        cursor = b;
+                        page_end = b + lzh::kMfPagePairs;
+                    }
                 }
             }
-            uint32_t *dst = arena + 2 * cursor;
-            const bool ovf = overflow;
-            auto emit = [&](uint32_t k, uint32_t len, uint32_t dist) {
-                if (lane == 0 && !ovf) {
-                    dst[2 * k] = len;
-                    dst[2 * k + 1] = dist;
-                }
-            };
-            const uint32_t c = lz::mf_find(t, P, inf, p0, p8, p16, js, je, emit, lane);
-            if (lane == 0) meta[P] = lz::mf_meta(cursor, c);
-            if (!overflow) cursor += c;
-            emitted += c;
+            lz::MfRowOut out;
+            out.dst = arena + 2 * cursor;
+            out.on = act && !overflow;
+            const uint32_t c = lz::mf_find4(t, P, inf, p0, p8, p16, js, je, act, out, lane);
+            if (act) {
+                if (idx == 0) meta[P] = lz::mf_meta(cursor, c);
+                if (!overflow) cursor += c;
+                emitted += c;
+            }
         }
     }
-    if (lane == 0) {
+    if (idx == 0) {
         if (overflow) atomicAdd(&ctrl[1], 1ull);
         atomicAdd(&ctrl[2], (unsigned long long)emitted);
     }
@@ -442,7 +456,7 @@ int MfResult::reserve(uint32_t n) {
     const size_t n1 = n ? n : 1;
     LZ_HIP(meta.alloc(n1 * 8));
     LZ_HIP(ctrl.alloc(3 * 8));
-    const uint64_t want = (uint64_t)n1 * 5 + (uint64_t)scan_blocks((uint32_t)n1) * 4 * kMfPagePairs;
+    const uint64_t want = (uint64_t)n1 * 5 + (uint64_t)scan_blocks((uint32_t)n1) * 16 * kMfPagePairs;
     LZ_HIP(arena.alloc(want * 8));
     arena_pairs = want;
     cap = (uint32_t)n1;
@@ -460,7 +474,7 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
     int rc = r.reserve(n);
     if (rc) return rc;
     const unsigned blocks = scan_blocks(n);
-    const uint64_t nwaves = (uint64_t)blocks * 4;
+    const uint64_t nrows = (uint64_t)blocks * 16;  // 16-lane rows, each with an arena page of its own
     for (int attempt = 0; attempt < 8; attempt++) {
         LZ_HIP(hipMemsetAsync(r.ctrl.p, 0, 3 * 8, st));
         hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks), dim3(256), 0, st, s.view, d_job_off, base, j0,
@@ -476,7 +490,7 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
         }
         // the emitted count is exact even when the arena overflowed; growing the arena frees
         // the old one, which waits for every kernel on the device
-        const uint64_t want = h[2] + h[2] / 16 + nwaves * kMfPagePairs;
+        const uint64_t want = h[2] + h[2] / 8 + nrows * kMfPagePairs;
         LZ_HIP(hipDeviceSynchronize());
         LZ_HIP(r.arena.alloc(want * 8));
         r.arena_pairs = want;

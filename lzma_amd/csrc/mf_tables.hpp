@@ -14,7 +14,7 @@
 
 namespace lzh {
 
-constexpr uint32_t kMfPagePairs = 8192;  // arena page: pairs a wave appends to before taking a new page
+constexpr uint32_t kMfPagePairs = 4096;  // arena page: pairs a 16-lane row appends to before taking a new page
 
 struct MfScratch {
     DevBuf ent4, ent8, ent16, info; // tables (see lzma_mf_core.hpp)
