@@ -110,6 +110,14 @@ int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off, si
                                const uint64_t *d_out_off, uint64_t *d_out_sizes,
                                int32_t *d_status, void *stream);
 
+/* The encoder keeps its streams and device memory (match-finder tables and match
+ * lists, up to about 250 bytes per input byte of the largest batch of chunks seen)
+ * with the calling thread from one call to the next, because allocating and
+ * releasing that much takes seconds.  This gives it back.  No counterpart in the
+ * reference (its encoder state lives and dies with each writer,
+ * lzma_encoder.go:1120-1136). */
+void lzma_amd_release_workspace(void);
+
 /* --------------------------------------------------------------------- decoder
  * Replaces decoder.decoder() run once per stream (lzma_decoder.go:306-349;
  * doDecode :218-304; range decoder range_coder.go:27-105; output window

@@ -23,7 +23,7 @@ EXPORTS = [
     "lzma_amd_last_error", "lzma_amd_version", "lzma_amd_encode_bound", "lzma_amd_bt4_matches",
     "lzma_amd_bt4_matches_dev", "lzma_amd_encode_chunks", "lzma_amd_encode_chunks_dev",
     "lzma_amd_decode_batch", "lzma_amd_decode_batch_dev", "lzma_amd_parse_header",
-    "lzma_amd_last_timing", "lzma_amd_last_coder_launches",
+    "lzma_amd_last_timing", "lzma_amd_last_coder_launches", "lzma_amd_release_workspace",
 ]
 
 
@@ -76,6 +76,11 @@ def lib():
 def check(rc):
     if rc != OK:
         raise NativeError(rc, lib().lzma_amd_last_error().decode("utf-8", "replace"))
+
+
+def release_workspace():
+    """Give back the device memory the calling thread's encoder keeps between calls."""
+    lib().lzma_amd_release_workspace()
 
 
 def last_timing():

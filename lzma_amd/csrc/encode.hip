@@ -7,11 +7,14 @@
 //      position of every chunk at full-chip throughput;
 //   2. encode_kernel runs the optimal parse and the range coder (lzma_enc_core.hpp),
 //      one wave per chunk, reading the lists as it goes.
-// A chunk's wave is a long dependent chain, so throughput comes from how many chains
-// a CU holds: the state kept in LDS is cut to 20 KiB (non-literal models, 16-bit
-// price tables, a 128-entry window of the optimum table, the current match list),
-// eight chunks per CU; the literal models (12 KiB at lc3) sit in HBM behind the L2,
-// which costs a chain about 2 % and buys twice the resident chains.
+// A chunk's wave is a long dependent chain (about 5 s per MiB), and the time of a chain
+// hardly changes with the number of chains next to it, so throughput comes from how
+// many chains a CU holds: the state kept in LDS is cut to 12.5 KiB at fb 128
+// (non-literal models, 16-bit price tables sized by the number of fast bytes, a
+// 64-entry window of the optimum table, the current match list), twelve chunks per CU
+// (the kernel's registers allow three waves per SIMD); the literal models (12 KiB at
+// lc 3) sit in HBM behind the L2, which costs a chain about 2 %.
+// The phases of successive batches overlap: see lzma_amd_encode_chunks_dev.
 //
 // Roofline class: HBM in principle (N bytes in, C bytes out per chunk);
 // serial-dependency-bound in practice.
@@ -185,25 +188,58 @@ struct Slot {
     lzh::DevBuf opt, lit;
     hipEvent_t e0 = nullptr, e1 = nullptr;  // around the batch's encode launch
     bool busy = false;
-    ~Slot() {
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
 };
 
 // The device gives a process four hardware queues: one for the finder and three for
 // encode launches, the caller's stream being one of the three (streams beyond that
 // would share a queue and run one after the other).
-struct Streams {
-    hipStream_t mf = nullptr, enc[kEncStreams] = {};
+//
+// Streams and device memory are kept by the calling thread from one call to the next
+// (about 250 bytes per input byte of the largest batch seen, up to some 190 GB for 1 MiB
+// chunks): allocating and releasing that much costs seconds per call.
+// lzma_amd_release_workspace() gives it back.
+struct Workspace {
+    int device = -1;
+    hipStream_t mf = nullptr, enc[kEncStreams] = {};  // enc[0] is the caller's, set per call
     hipEvent_t in_ready = nullptr;
-    ~Streams() {
+    lzh::MfScratch scratch;
+    Slot slots[kEncStreams + 1];
+    int prepare(int dev) {
+        if (device == dev) return LZMA_AMD_OK;
+        release();
+        LZ_HIP(hipStreamCreateWithFlags(&mf, hipStreamNonBlocking));
+        for (int i = 1; i < kEncStreams; i++) LZ_HIP(hipStreamCreateWithFlags(&enc[i], hipStreamNonBlocking));
+        LZ_HIP(hipEventCreateWithFlags(&in_ready, hipEventDisableTiming));
+        for (auto &sl : slots) {
+            LZ_HIP(hipEventCreate(&sl.e0));
+            LZ_HIP(hipEventCreate(&sl.e1));
+        }
+        device = dev;
+        return LZMA_AMD_OK;
+    }
+    void release() {
+        if (device < 0) return;
+        (void)hipDeviceSynchronize();
         if (mf) (void)hipStreamDestroy(mf);
-        for (int i = 1; i < kEncStreams; i++)  // enc[0] is the caller's
+        for (int i = 1; i < kEncStreams; i++)
             if (enc[i]) (void)hipStreamDestroy(enc[i]);
         if (in_ready) (void)hipEventDestroy(in_ready);
+        mf = nullptr, in_ready = nullptr;
+        for (auto &e : enc) e = nullptr;
+        for (auto &sl : slots) {
+            if (sl.e0) (void)hipEventDestroy(sl.e0);
+            if (sl.e1) (void)hipEventDestroy(sl.e1);
+            sl.e0 = sl.e1 = nullptr;
+            sl.res.release();
+            sl.opt.release(), sl.lit.release();
+            sl.busy = false;
+        }
+        scratch.release();
+        device = -1;
     }
 };
+// never destroyed on its own: at process exit the HIP runtime may already be gone
+thread_local Workspace *g_ws = nullptr;
 
 }  // namespace
 
@@ -283,27 +319,30 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     const unsigned grid_cap = std::max(1u, resident / in_flight);
     const unsigned max_grid = (unsigned)std::min<size_t>(max_chunks, grid_cap);
 
-    Streams S;
-    LZ_HIP(hipStreamCreateWithFlags(&S.mf, hipStreamNonBlocking));
+    int dev = 0;
+    LZ_HIP(hipGetDevice(&dev));
+    if (!g_ws) g_ws = new Workspace;
+    Workspace &S = *g_ws;
+    if ((rc = S.prepare(dev))) return rc;
     S.enc[0] = st;
-    for (int i = 1; i < (int)in_flight; i++) LZ_HIP(hipStreamCreateWithFlags(&S.enc[i], hipStreamNonBlocking));
-    LZ_HIP(hipEventCreateWithFlags(&S.in_ready, hipEventDisableTiming));
     // whatever the caller enqueued on its stream (the inputs) comes first
     LZ_HIP(hipEventRecord(S.in_ready, st));
     LZ_HIP(hipStreamWaitEvent(S.mf, S.in_ready, 0));
     for (int i = 1; i < (int)in_flight; i++) LZ_HIP(hipStreamWaitEvent(S.enc[i], S.in_ready, 0));
 
     // all memory up front: nothing is allocated or freed while launches are in flight
-    lzh::MfScratch scratch;
+    lzh::MfScratch &scratch = S.scratch;
     if ((rc = scratch.reserve((uint32_t)max_bytes))) return rc;
     const int nslots = (int)std::min<size_t>(nbatches, in_flight + 1);
-    std::vector<Slot> slots(nslots);
-    for (auto &sl : slots) {
+    Slot *slots = S.slots;
+    for (int i = 0; i < nslots; i++) {
+        Slot &sl = slots[i];
+        sl.busy = false;
         if ((rc = sl.res.reserve((uint32_t)max_bytes))) return rc;
-        LZ_HIP(sl.opt.alloc((size_t)max_grid * lz::kNumOpts * sizeof(lz::OptG)));
-        LZ_HIP(sl.lit.alloc((size_t)max_grid * lit_stride * sizeof(lz::prob_t)));
-        LZ_HIP(hipEventCreate(&sl.e0));
-        LZ_HIP(hipEventCreate(&sl.e1));
+        const size_t opt_bytes = (size_t)max_grid * lz::kNumOpts * sizeof(lz::OptG);
+        const size_t lit_bytes = (size_t)max_grid * lit_stride * sizeof(lz::prob_t);
+        if (sl.opt.bytes < opt_bytes) LZ_HIP(sl.opt.alloc(opt_bytes));
+        if (sl.lit.bytes < lit_bytes) LZ_HIP(sl.lit.alloc(lit_bytes));
     }
     lzh::Timer t_all;
     t_all.start(S.mf);
@@ -317,9 +356,14 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         sl.busy = false;
         return LZMA_AMD_OK;
     };
+    // an error while launches are in flight: let them finish before the caller gets its buffers back
+    auto bail = [&](int code) -> int {
+        (void)hipDeviceSynchronize();
+        return code;
+    };
     for (size_t b = 0; b < nbatches; b++) {
         Slot &sl = slots[b % nslots];
-        if ((rc = retire(sl))) return rc;  // its previous batch must be encoded before its lists go
+        if ((rc = retire(sl))) return bail(rc);  // its previous batch must be encoded before its lists go
         const size_t c0 = cut[b], c1 = cut[b + 1];
         const uint64_t base = off[c0];
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
@@ -328,9 +372,10 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         // the sort temporaries live in the arena the scan is about to fill
         if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
                                 sl.res.arena.bytes)))
-            return rc;
+            return bail(rc);
         uint64_t total_pairs = 0;
-        if ((rc = lzh::mf_scan(scratch, sl.res, d_in_off, base, c0, nchunks, S.mf, &total_pairs))) return rc;
+        if ((rc = lzh::mf_scan(scratch, sl.res, d_in_off, base, c0, nchunks, S.mf, &total_pairs)))
+            return bail(rc);
         t_mf[b].stop();
         // the finder stream is idle here (mf_scan synchronized it): the lists are complete
         hipStream_t es = S.enc[b % in_flight];
@@ -345,8 +390,8 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         sl.busy = true;
         ts.coder_launches++;
     }
-    for (auto &sl : slots)
-        if ((rc = retire(sl))) return rc;
+    for (int i = 0; i < nslots; i++)
+        if ((rc = retire(slots[i]))) return rc;
     t_all.stop();
     LZ_HIP(hipStreamSynchronize(S.mf));
     for (int i = 0; i < (int)in_flight; i++) LZ_HIP(hipStreamSynchronize(S.enc[i]));
@@ -356,6 +401,10 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     ts.ms_coder = ms_coder;
     ts.ms_total = t_all.ms();
     return LZMA_AMD_OK;
+}
+
+extern "C" void lzma_amd_release_workspace(void) {
+    if (g_ws) g_ws->release();
 }
 
 extern "C" int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off, size_t n_chunks,

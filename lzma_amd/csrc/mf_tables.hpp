@@ -34,6 +34,10 @@ struct MfScratch {
     // arena the scan will fill), else to an allocation of their own.
     int build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st,
               void *tmp = nullptr, size_t tmp_cap = 0);
+    void release() {
+        ent4.release(), ent8.release(), ent16.release(), info.release(), own_tmp.release();
+        cap = 0;
+    }
 };
 
 struct MfResult {
@@ -41,6 +45,10 @@ struct MfResult {
     uint64_t arena_pairs = 0;
     uint32_t cap = 0;
     int reserve(uint32_t n);
+    void release() {
+        meta.release(), arena.release(), ctrl.release();
+        arena_pairs = 0, cap = 0;
+    }
     const uint64_t *d_meta() const { return meta.as<uint64_t>(); }
     const uint32_t *d_arena() const { return arena.as<uint32_t>(); }
 };
