@@ -41,7 +41,7 @@ struct MfEnt {
 };
 // Per position: its index in the three tables with the index of the first entry of
 // its bucket / group in each, and the previous position with the same hash-2 / hash-3
-// slot (kNone if there is none).
+// slot if it starts with the same byte (kNone otherwise).
 struct __attribute__((aligned(16))) MfInfo {
     uint32_t rank4, g4, rank8, g8;
     uint32_t rank16, g16, prev2, prev3;
@@ -225,7 +225,7 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
 // reference drops seed pairs that way).
 //
 // Everything that can be addressed from inf -- the 16 newest entries of the bucket, of
-// the 8-gram group and of the 16-gram group, the two seed bytes -- is requested in one
+// the 8-gram group and of the 16-gram group -- is requested in one
 // batch, so a typical position costs one memory round trip.
 LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_t p0, uint64_t p8,
                        uint64_t p16, uint32_t job_start, uint32_t job_end, bool act, const MfRowOut &out,
@@ -234,7 +234,6 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_
     const uint32_t left = act ? job_end - P : 0;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
     act = act && len_limit >= 4;  // lz_bin_tree.go:121-124
-    const uint8_t *data = t.data;
     // candidate Q is inside the window iff P - Q <= dict (cyclicBufSize = dict+1, :128-131)
     uint32_t W = P > t.dict ? P - t.dict : 0;
     if (W < job_start) W = job_start;
@@ -250,24 +249,22 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_
     if (act && idx < r4 - g4) a0 = t.ent4[r4 - 1 - idx];
     if (use8 && idx < r8 - g8) b0 = t.ent8[r8 - 1 - idx];
     if (use16 && idx < r16 - g16) c0 = t.ent16[r16 - 1 - idx];
-    uint32_t b2 = 0x100, b3 = 0x100;
-    if (act && q2 != kNone && q2 >= W) b2 = data[q2];
-    if (act && q3 != kNone && q3 >= W) b3 = data[q3];
+    // inf.prev2 / prev3 are kNone unless that position starts with P's first byte
+    const bool hit2 = act && q2 != kNone && q2 >= W, hit3 = act && q3 != kNone && q3 >= W;
 
     const uint32_t a_new = row_first(a0.pos, row_base), b_new = row_first(b0.pos, row_base),
                    c_new = row_first(c0.pos, row_base);
     uint32_t q4 = kNone;
     if (act && r4 > g4 && a_new >= job_start) q4 = a_new;
-    const uint32_t b0byte = (uint32_t)p0 & 0xFF;
     uint32_t n = 0, max_len = 1, last = q2;
     const bool lead = idx == 0 && out.on;
     // seeds, lz_bin_tree.go:154-180
-    if (b2 == b0byte) {
+    if (hit2) {
         max_len = 2;
         if (lead) out.dst[0] = 2u, out.dst[1] = P - q2 - 1;
         n = 1;
     }
-    if (b3 == b0byte) {
+    if (hit3) {
         if (q3 == q2) n--;
         max_len = 3;
         if (lead) out.dst[2 * n] = 3u, out.dst[2 * n + 1] = P - q3 - 1;

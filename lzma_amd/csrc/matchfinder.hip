@@ -54,11 +54,11 @@ __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__
                            b3 = (w >> 24) & 0xFF;
             uint32_t t = crc[b0] ^ b1;  // lz_bin_tree.go:139-143
             if (KIND == KEY2) {
-                keys[i] = (K)(t & (lz::kHash2Size - 1));
+                keys[i] = (K)((t & (lz::kHash2Size - 1)) | (b0 << 24));  // first byte rides along, unsorted
             } else {
                 t ^= b2 << 8;
                 if (KIND == KEY3)
-                    keys[i] = (K)(t & (lz::kHash3Size - 1));
+                    keys[i] = (K)((t & (lz::kHash3Size - 1)) | (b0 << 24));
                 else
                     keys[i] = (K)((t ^ (crc[b3] << 5)) & mask);
             }
@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__
     }
 }
 
-// prev of ord[j] = ord[j-1] if it has the same key, else kNone
+// prev of ord[j] = ord[j-1] if it is in the same hash slot AND starts with the same byte, else
+// kNone.  The reference looks at the slot's most recent position only and reports it if the
+// first bytes agree (lz_bin_tree.go:154-172), so a head whose first byte differs is the same
+// as no head; deciding that here (the first byte rides in bits 24..31 of the key, outside the
+// sorted bits) saves the scan two random one-byte reads per position.
 template <int WHICH>
 __global__ __launch_bounds__(256) void mf_prev_kernel(const uint32_t *__restrict__ ord,
                                                       const uint32_t *__restrict__ skey, uint32_t n,
