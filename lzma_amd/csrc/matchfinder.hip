@@ -213,7 +213,7 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 // Each row of a wave walks its own run of consecutive positions and appends their pairs to
 // a private page of the arena (one atomic per page); the result word of a position says
 // where its pairs are.
-__global__ __launch_bounds__(256) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+__global__ __launch_bounds__(256, 8) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
