@@ -213,13 +213,15 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 // Each row of a wave walks its own run of consecutive positions and appends their pairs to
 // a private page of the arena (one atomic per page); the result word of a position says
 // where its pairs are.
-__global__ __launch_bounds__(256, 8) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+__global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
                                                       unsigned long long *ctrl) {
-    const uint32_t lane = threadIdx.x & 63, idx = lane & 15, row = lane >> 4, row_base = lane & 48;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t lane = threadIdx.x, idx = lane & 15, row = lane >> 4, row_base = lane & 48;
+    // one wave per workgroup: next to resident encode waves a SIMD often has room for one more
+    // wave but not all four SIMDs of a CU at once, which a larger workgroup would need
+    const uint32_t wave = blockIdx.x, nwaves = gridDim.x;
     const uint32_t n = t.n;
     const uint32_t nruns = (n + kRun - 1) / kRun;
     uint64_t cursor = 0, page_end = 0;  // the row's arena page
@@ -481,7 +483,7 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
     const uint64_t nrows = (uint64_t)blocks * 16;  // 16-lane rows, each with an arena page of its own
     for (int attempt = 0; attempt < 8; attempt++) {
         LZ_HIP(hipMemsetAsync(r.ctrl.p, 0, 3 * 8, st));
-        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks), dim3(256), 0, st, s.view, d_job_off, base, j0,
+        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off, base, j0,
                            njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
                            r.ctrl.as<unsigned long long>());
         LZ_HIP(hipGetLastError());
