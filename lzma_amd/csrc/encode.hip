@@ -204,6 +204,12 @@ struct Workspace {
     hipEvent_t in_ready = nullptr;
     lzh::MfScratch scratch;
     Slot slots[kEncStreams + 1];
+    uint64_t bytes() const {
+        uint64_t b = scratch.ent4.bytes + scratch.ent8.bytes + scratch.ent16.bytes + scratch.info.bytes +
+                     scratch.own_tmp.bytes;
+        for (const auto &sl : slots) b += sl.res.meta.bytes + sl.res.arena.bytes + sl.opt.bytes + sl.lit.bytes;
+        return b;
+    }
     int prepare(int dev) {
         if (device == dev) return LZMA_AMD_OK;
         release();
@@ -293,10 +299,19 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
 
     // batches: whole chunks, at most batch_bytes each (a larger chunk is a batch of its own)
     const uint64_t total = off[n_chunks] - off[0];
-    uint64_t batch_bytes = 768ull << 20;
+    uint64_t batch_bytes = 832ull << 20;
     int enc_streams = kEncStreams;
     if (const char *e = getenv("LZMA_AMD_BATCH_MIB")) batch_bytes = (uint64_t)atoi(e) << 20;
     if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
+    {   // a batch costs about 68 B per position of finder tables plus 48 B per position and 1.1 GB
+        // for each of the four match-list slots: shrink it to what the device has free (the
+        // thread's kept workspace counts as free, it is reused)
+        size_t free_b = 0, total_b = 0;
+        LZ_HIP(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t avail = (uint64_t)free_b + (g_ws ? g_ws->bytes() : 0);
+        auto need = [](uint64_t b) { return 68 * b + 4 * (48 * b + 1100000000ull) + (1ull << 30); };
+        while (batch_bytes > (64ull << 20) && need(batch_bytes) > avail - avail / 16) batch_bytes -= 64ull << 20;
+    }
     // with large chunks a batch holds a third of the resident workgroups, so that three
     // launches fill the device
     const size_t batch_chunks = n_chunks > resident ? std::max(1u, resident / enc_streams) : resident;
