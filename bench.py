@@ -45,7 +45,7 @@ def pmc_traffic(kernel, input_bytes_per_launch):
     """HBM bytes per launch of `kernel`, from the committed rocprofv3 PMC summary of this
     workload (FETCH_SIZE + WRITE_SIZE per input byte, measured in separate counter runs),
     scaled to this run's launch size.  None if there is no summary."""
-    path = ROOT / "profiles" / "r01_pmc_encode_768x1MiB.json"
+    path = ROOT / "profiles" / "r01_pmc_encode_832x1MiB.json"
     try:
         k = json.loads(path.read_text())["kernels"][kernel]
     except (OSError, KeyError, ValueError):
