@@ -195,7 +195,7 @@ struct Slot {
 // would share a queue and run one after the other).
 //
 // Streams and device memory are kept by the calling thread from one call to the next
-// (about 250 bytes per input byte of the largest batch seen, up to some 190 GB for 1 MiB
+// (about 250 bytes per input byte of the largest batch seen, up to some 230 GB for 1 MiB
 // chunks): allocating and releasing that much costs seconds per call.
 // lzma_amd_release_workspace() gives it back.
 struct Workspace {
