@@ -219,7 +219,8 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
 }
 
 // Match lists of four positions, one per row.  P, inf (= t.info[P]), the text bytes p0 /
-// p8 / p16 (bytes 0..7, 8..15, 16..23 at P) and the job [job_start, job_end) are per row;
+// p8 / p16 (bytes 0..7, 8..15, 16..23 at P, zero beyond the buffer) and the job
+// [job_start, job_end) are per row;
 // rows with act == false take no part.  Returns the row's number of pairs; the pairs
 // themselves are written through `out` (a later pair with a smaller index overwrites: the
 // reference drops seed pairs that way).

@@ -234,9 +234,6 @@ __global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const ui
         const bool row_on = p_begin < n;
         // job containing p_begin: last j with job_off[j] - base <= p_begin
         uint32_t job = 0, js = 0, je = 0;
-        lz::MfInfo inf_next = {};
-        uint64_t w0 = 0, w1 = 0, w2 = 0;  // bytes 0..23 at P, rolled along by one byte per position
-        uint32_t byte_next = 0;
         if (row_on) {
             uint32_t lo = 0, hi = njobs;  // invariant: off[lo] <= p_begin < off[hi]
             while (hi - lo > 1) {
@@ -245,23 +242,18 @@ __global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const ui
             }
             job = lo;
             js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
-            inf_next = t.info[p_begin];
-            w0 = lz::mf_load8(t.data, n, p_begin), w1 = lz::mf_load8(t.data, n, p_begin + 8);
-            w2 = lz::mf_load8(t.data, n, p_begin + 16);
-            byte_next = p_begin + 24 < n ? t.data[p_begin + 24] : 0;
         }
         for (uint32_t k = 0; k < kRowRun; k++) {
             const uint32_t P = p_begin + k;
             const bool act = row_on && P < p_end;
             if (!__any(act)) break;
-            const lz::MfInfo inf = inf_next;
-            const uint64_t p0 = w0, p8 = w1, p16 = w2;
-            const uint32_t bn = byte_next;
-            if (act && P + 1 < p_end) {
-                inf_next = t.info[P + 1];
-                byte_next = P + 25 < n ? t.data[P + 25] : 0;
+            lz::MfInfo inf = {};
+            if (act) inf = t.info[P];
+            uint64_t p0 = 0, p8 = 0, p16 = 0;  // bytes 0..7, 8..15, 16..23 at P
+            if (act) {
+                p0 = lz::mf_load8(t.data, n, P), p8 = lz::mf_load8(t.data, n, P + 8);
+                p16 = lz::mf_load8(t.data, n, P + 16);
             }
-            w0 = (w0 >> 8) | (w1 << 56), w1 = (w1 >> 8) | (w2 << 56), w2 = (w2 >> 8) | ((uint64_t)bn << 56);
             if (act)
                 while (P >= je) {  // empty jobs are skipped
                     job++;
