@@ -21,6 +21,7 @@
 // Roofline class: HBM (N input bytes read, 4N count bytes + 8 bytes per pair
 // written).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -454,7 +455,13 @@ int MfResult::reserve(uint32_t n) {
     const size_t n1 = n ? n : 1;
     LZ_HIP(meta.alloc(n1 * 8));
     LZ_HIP(ctrl.alloc(3 * 8));
-    const uint64_t want = (uint64_t)n1 * 5 + (uint64_t)scan_blocks((uint32_t)n1) * 16 * kMfPagePairs;
+    // first estimate: 5 pairs per position (text has about 4.5) plus one page per row; the scan
+    // reports the exact need if this is too small.  LZMA_AMD_ARENA_TEST=1 starts from a
+    // deliberately small arena (pages for half of the rows) so that tests reach the grow-and-retry
+    // path, and reports each growth on stderr.
+    const char *tiny = getenv("LZMA_AMD_ARENA_TEST");
+    const uint64_t rows = (uint64_t)scan_blocks((uint32_t)n1) * 16;
+    const uint64_t want = (tiny && tiny[0] == '1') ? rows * kMfPagePairs / 2 : (uint64_t)n1 * 5 + rows * kMfPagePairs;
     LZ_HIP(arena.alloc(want * 8));
     arena_pairs = want;
     cap = (uint32_t)n1;
@@ -489,6 +496,8 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
         // the emitted count is exact even when the arena overflowed; growing the arena frees
         // the old one, which waits for every kernel on the device
         const uint64_t want = h[2] + h[2] / 8 + nrows * kMfPagePairs;
+        if (const char *tiny = getenv("LZMA_AMD_ARENA_TEST"))
+            if (tiny[0] == '1') fprintf(stderr, "lzma_amd: arena grown to %llu pairs\n", (unsigned long long)want);
         LZ_HIP(hipDeviceSynchronize());
         LZ_HIP(r.arena.alloc(want * 8));
         r.arena_pairs = want;

@@ -77,3 +77,41 @@ def test_match_lists_are_matches(kind, dict_size, fb):
     m = k - 1
     assert np.array_equal(counts[:m], c_ref[:m])
     assert np.array_equal(pairs[: int(offs[m])], p_ref[: int(c_ref[:m].sum())])
+
+
+def test_arena_grow_and_retry():
+    """The match-list arena starts from an estimate; when a batch needs more the scan is
+    repeated with the exact size.  Reached here by starting from a deliberately small arena
+    (in a child process: the setting is read when the arena is first allocated)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import lzma_amd
+from oracle import oracle as O
+from tests import synth
+n = 48 << 20
+data = synth.markov(n, cfg=1)
+counts, pairs = lzma_amd.bt4_matches(data.tobytes(), 1 << 20, 64)
+assert pairs.shape[0] == int(counts.sum())
+k = 1 << 19
+c_ref, p_ref = O.bt4_matches(data[:k + 64].tobytes(), 1 << 20, 64, 1 << 30)
+assert np.array_equal(counts[:k - 1], c_ref[:k - 1])
+assert np.array_equal(pairs[: int(counts[:k - 1].sum())], p_ref[: int(c_ref[:k - 1].sum())])
+chunks = [bytes(data[i << 20:(i + 1) << 20]) for i in range(40)]
+st, outs = lzma_amd.encode_chunks(chunks, lzma_amd.make_params(22, 128))
+assert (st == 0).all()
+st2, dec = lzma_amd.decode_batch(outs)
+assert (st2 == 0).all() and dec == chunks
+want = O.encode(chunks[3], O.params(dict_log=22, fb=128, lc=3, lp=0, pb=2, cut=1 << 30, eos=False))
+assert outs[3] == want
+print("retry ok")
+'''
+    import os
+    env = dict(os.environ, LZMA_AMD_ARENA_TEST="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "retry ok" in r.stdout, r.stdout + r.stderr
+    assert r.stderr.count("arena grown") >= 2, r.stderr  # the finder call and the encoder call both grew it
