@@ -177,6 +177,7 @@ int check_params(const lzma_amd_params *p) {  // checkValues, lzma_encoder.go:11
 }
 
 constexpr uint64_t kMaxChunkBytes = 1ull << 30;  // largest single chunk
+constexpr uint64_t kMinBatchBytes = 128ull << 20; // a batch is not cut below this for its chunk count
 constexpr unsigned kNumCU = 256;
 constexpr unsigned kLdsPerCU = 160u << 10;
 constexpr unsigned kMaxChainsPerCU = 12;          // three waves per SIMD at the kernel's register count
@@ -313,12 +314,14 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         while (batch_bytes > (64ull << 20) && need(batch_bytes) > avail - avail / 16) batch_bytes -= 64ull << 20;
     }
     // with large chunks a batch holds a third of the resident workgroups, so that three
-    // launches fill the device
+    // launches fill the device; small chunks are batched by size alone (a launch loops over them)
     const size_t batch_chunks = n_chunks > resident ? std::max(1u, resident / enc_streams) : resident;
     std::vector<size_t> cut{0};
     for (size_t c = 0; c < n_chunks;) {
         size_t c1 = c + 1;
-        while (c1 < n_chunks && off[c1 + 1] - off[c] <= batch_bytes && c1 - c < batch_chunks) c1++;
+        while (c1 < n_chunks && off[c1 + 1] - off[c] <= batch_bytes &&
+               (c1 - c < batch_chunks || off[c1] - off[c] < kMinBatchBytes))
+            c1++;
         cut.push_back(c1);
         c = c1;
     }
