@@ -2,36 +2,45 @@
 // concurrently, one 64-lane wavefront (= one workgroup) per stream.
 //
 // Replaces decoder.decoder()/doDecode of the reference (lzma_decoder.go:218-349)
-// applied once per stream.  The probability models of a stream (15.6 KiB at
-// lc+lp <= 3) live in LDS, so ten streams are resident per CU; the range-decoder
-// state is wave-uniform and is kept in scalar registers; the match copy is done
-// by all 64 lanes.  Streams whose literal coder does not fit in LDS (lc+lp > 3)
-// are deferred to a second, persistent launch that keeps the literal models in a
-// per-workgroup HBM scratch area.
+// applied once per stream.  A stream is a serial chain, and the throughput of the device
+// grows almost linearly with the number of streams a CU holds (measured from 2 to 10 per
+// CU), so the state kept in LDS is cut to the 3.6 KiB of non-literal models and a CU holds
+// 32 streams, as many as it has wave slots.  The literal models (12 KiB at lc 3) live in a per-workgroup HBM area behind the L2
+// and are walked in registers, one fetch per literal (lzma_dec_core.hpp).  The
+// range-decoder state is wave-uniform and is kept in scalar registers; the match copy is
+// done by all 64 lanes.  Each workgroup owns one literal area and loops over the streams
+// blockIdx, blockIdx + gridDim, ...  Streams whose literal coder is larger than the area (lc+lp > 4) are
+// deferred to a second launch with few workgroups and full-size areas.
 //
 // Roofline class: HBM-bound in principle (reads C compressed bytes, writes N raw
 // bytes per stream), serial-dependency-bound in practice.
+#include <algorithm>
+
 #include "host_util.hpp"
 #include "lzma_dec_core.hpp"
 
 namespace {
 
-constexpr uint32_t kLitLdsLog = 3;                      // lc+lp handled from LDS
-constexpr uint32_t kLitLds = 0x300u << kLitLdsLog;      // 6144 models
-constexpr uint32_t kLdsProbs = lz::kNumBaseProbs + kLitLds;
+constexpr uint32_t kLitSmallLog = 4;                     // lc+lp handled by the first launch
+constexpr uint64_t kLitSmall = 0x300ull << kLitSmallLog;  // models per workgroup area, first launch
+constexpr uint64_t kLitBig = 0x300ull << 12;              // ... second launch (lc <= 8, lp <= 4)
+// Workgroups of the first launch: one per stream up to this many (3 GiB of literal areas).  Far
+// more than are resident (32 per CU): streams differ in length, and workgroups that wait in the
+// dispatcher's queue balance the load better than resident ones looping over a fixed share.
+constexpr uint64_t kMaxGrid = 131072;
 constexpr int32_t kPending = -1;
 
-// One workgroup (one wave) per stream.  BIG == false: grid = n_streams, streams
-// with lc+lp > kLitLdsLog are appended to big_list.  BIG == true: persistent grid
-// over big_list, literal models in lit_scratch[blockIdx].
+// BIG == false: all streams; those with lc+lp > kLitSmallLog are
+// appended to big_list.  BIG == true: persistent grid over big_list.
 template <bool BIG>
 __global__ __launch_bounds__(64) void decode_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint64_t n_streams,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint32_t *big_count,
     uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride) {
-    __shared__ lz::prob_t s_probs[BIG ? lz::kNumBaseProbs : kLdsProbs];
+    __shared__ __align__(16) lz::prob_t s_probs[lz::kNumBaseProbs];
     const uint32_t lane = threadIdx.x;
+    lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_scratch_stride;
 
     uint64_t first = blockIdx.x, step = gridDim.x;
     uint64_t count = BIG ? (uint64_t)*big_count : n_streams;
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(64) void decode_kernel(
             continue;
         }
         const uint32_t lit_n = 0x300u << (h.lc + h.lp);
-        if (!BIG && h.lc + h.lp > kLitLdsLog) {
+        if (!BIG && h.lc + h.lp > kLitSmallLog) {
             if (lane == 0) {
                 uint32_t k = atomicAdd(big_count, 1u);
                 big_list[k] = (uint32_t)s;
@@ -61,18 +70,12 @@ __global__ __launch_bounds__(64) void decode_kernel(
         }
         __syncthreads();  // previous stream's models are no longer in use
         for (uint32_t i = lane; i < lz::kNumBaseProbs; i += 64) s_probs[i] = lz::kProbInit;
-        lz::DecodeResult r;
-        if (BIG) {
-            lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_scratch_stride;
-            for (uint32_t i = lane; i < lit_n; i += 64) lit[i] = lz::kProbInit;
-            __syncthreads();
-            r = lz::decode_stream(sin, n, h, s_probs, lit, out + ob, oe - ob, lane, 64u);
-        } else {
-            for (uint32_t i = lane; i < lit_n; i += 64) s_probs[lz::P_LIT + i] = lz::kProbInit;
-            __syncthreads();
-            r = lz::decode_stream(sin, n, h, s_probs, s_probs + lz::P_LIT, out + ob, oe - ob, lane,
-                                  64u);
+        {   // two models per store
+            uint32_t *lw = (uint32_t *)lit;
+            for (uint32_t i = lane; i < lit_n / 2; i += 64) lw[i] = lz::kProbInit * 0x10001u;
         }
+        __syncthreads();
+        const lz::DecodeResult r = lz::decode_stream<true>(sin, n, h, s_probs, lit, out + ob, oe - ob, lane, 64u);
         if (lane == 0) {
             status[s] = r.status;
             out_sizes[s] = r.out_size;
@@ -97,12 +100,14 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     lzh::DevBuf big;  // [0] = count, [1..] = list of deferred stream indices
     LZ_HIP(big.alloc((n_streams + 1) * sizeof(uint32_t)));
     LZ_HIP(hipMemsetAsync(big.p, 0, sizeof(uint32_t), st));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, kMaxGrid);
+    lzh::DevBuf lit_small;
+    LZ_HIP(lit_small.alloc((size_t)grid * kLitSmall * sizeof(lz::prob_t)));
     lzh::Timer tm;
     tm.start(st);
-    hipLaunchKernelGGL(decode_kernel<false>, dim3((unsigned)n_streams), dim3(64), 0, st, d_in,
-                       d_in_off, (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
-                       big.as<uint32_t>(), big.as<uint32_t>() + 1, (lz::prob_t *)nullptr,
-                       (uint64_t)0);
+    hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
+                       (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big.as<uint32_t>(),
+                       big.as<uint32_t>() + 1, lit_small.as<lz::prob_t>(), kLitSmall);
     LZ_HIP(hipGetLastError());
     uint32_t n_big = 0;
     LZ_HIP(hipMemcpyAsync(&n_big, big.p, sizeof n_big, hipMemcpyDeviceToHost, st));
@@ -110,12 +115,10 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     lzh::DevBuf scratch;
     if (n_big > 0) {
         const unsigned wgs = n_big < 64 ? n_big : 64;
-        const uint64_t stride = 0x300ull << 12;  // lc+lp <= 12 (lc <= 8, lp <= 4)
-        LZ_HIP(scratch.alloc((size_t)wgs * stride * sizeof(lz::prob_t)));
+        LZ_HIP(scratch.alloc((size_t)wgs * kLitBig * sizeof(lz::prob_t)));
         hipLaunchKernelGGL(decode_kernel<true>, dim3(wgs), dim3(64), 0, st, d_in, d_in_off,
                            (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
-                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(),
-                           stride);
+                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(), kLitBig);
         LZ_HIP(hipGetLastError());
     }
     tm.stop();

@@ -114,6 +114,83 @@ LZ_HD uint32_t bt_rev_decode(RangeDec &r, P *probs, uint32_t base, uint32_t nbit
     }
     return res;
 }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+// ---- literal coder walked in registers (GPU only)
+// The literal models are too large to keep every stream's in LDS without giving up most
+// of the streams a CU could hold, and decoding a literal from models in HBM one bit at a
+// time would cost a memory round trip per bit.  Instead the 256 models of a literal bit
+// tree are fetched at once, two 16-bit models per 32-bit word, word j of the tree in lane
+// j and word j + 64 in a second register; the walk picks each model out of the lanes with
+// a readlane, the lane that holds it keeps the updated value, and the words that changed
+// are stored back when the symbol is complete.
+struct TreeW {
+    uint32_t w0, w1;
+    bool d0, d1;  // this lane's word was updated
+};
+// the models base .. base + 255 (node k of the tree is model base + k); base is even
+template <class L>
+LZ_D TreeW tree_load(const L *lit, uint32_t base, uint32_t lane) {
+    const uint32_t *wp = (const uint32_t *)(lit + base);
+    TreeW t;
+    t.w0 = wp[lane];
+    t.w1 = wp[lane + 64];
+    t.d0 = t.d1 = false;
+    return t;
+}
+template <class L>
+LZ_D void tree_store(L *lit, uint32_t base, uint32_t lane, const TreeW &t) {
+    uint32_t *wp = (uint32_t *)(lit + base);
+    if (t.d0) wp[lane] = t.w0;
+    if (t.d1) wp[lane + 64] = t.w1;
+}
+// decodeBit (range_coder.go:75-105) on node k of a loaded tree
+LZ_D uint32_t tree_bit(RangeDec &r, TreeW &t, uint32_t k, uint32_t lane) {
+    const uint32_t word = k >> 1, src = word & 63u, sh = (k & 1u) << 4;
+    const bool second = word >= 64;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)(second ? t.w1 : t.w0), (int)src);
+    const uint32_t pr = (w >> sh) & 0xFFFFu;
+    const uint32_t bound = (r.range >> kProbBits) * pr;
+    uint32_t bit, np;
+    if (r.code < bound) {
+        r.range = bound;
+        np = pr + ((kProbTotal - pr) >> kMoveBits);
+        bit = 0;
+    } else {
+        r.range -= bound;
+        r.code -= bound;
+        np = pr - (pr >> kMoveBits);
+        bit = 1;
+    }
+    const uint32_t nw = (w & ~(0xFFFFu << sh)) | (np << sh);
+    if (lane == src) {
+        if (second) t.w1 = nw, t.d1 = true; else t.w0 = nw, t.d0 = true;
+    }
+    rd_normalize(r);
+    return bit;
+}
+// litSubCoder.decodeNormal / decodeWithMatchByte, lzma_lit_coder.go:18-44
+template <class L>
+LZ_D uint32_t lit_decode_regs(RangeDec &r, L *lit, uint32_t sub, bool matched, uint32_t mb, uint32_t lane) {
+    TreeW a = tree_load(lit, sub, lane);
+    uint32_t sym = 1;
+    if (matched) {
+        TreeW b0 = tree_load(lit, sub + 0x100u, lane), b1 = tree_load(lit, sub + 0x200u, lane);
+        while (sym < 0x100) {
+            const uint32_t mbit = (mb >> 7) & 1;
+            mb <<= 1;
+            const uint32_t b = mbit ? tree_bit(r, b1, sym, lane) : tree_bit(r, b0, sym, lane);
+            sym = (sym << 1) | b;
+            if (mbit != b) break;
+        }
+        tree_store(lit, sub + 0x100u, lane, b0);
+        tree_store(lit, sub + 0x200u, lane, b1);
+    }
+    while (sym < 0x100) sym = (sym << 1) | tree_bit(r, a, sym, lane);
+    tree_store(lit, sub, lane, a);
+    return sym;
+}
+#endif
+
 // lenCoder.decode, lzma_len_coder.go:28-46.
 template <class P>
 LZ_HD uint32_t len_decode(RangeDec &r, P *probs, uint32_t base, uint32_t pos_state) {
@@ -134,7 +211,8 @@ struct DecodeResult {
 // array.  All models must already be initialised to kProbInit.
 // lane/nlanes: the calling lane's index and the number of lanes executing this
 // call together (64 on the GPU, 1 on the host).
-template <class P, class L>
+// LIT_REGS (GPU only): the literal models are in HBM and are walked in registers.
+template <bool LIT_REGS = false, class P, class L>
 LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h, P *probs, L *lit,
                                  uint8_t *out, uint64_t out_cap, uint32_t lane, uint32_t nlanes) {
     DecodeResult res;
@@ -170,6 +248,14 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
             // litCoder.getSubCoder, lzma_lit_coder.go:126-128
             uint32_t sub = ((((uint32_t)now & lp_mask) << lc) + (prev >> (8 - lc))) * 0x300u;
             uint32_t sym = 1;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+            if (LIT_REGS) {
+                const bool matched = !st_is_char(state);
+                uint32_t mb = 0;
+                if (matched && (uint64_t)rep0 < now) mb = uni(out[now - 1 - rep0]);
+                sym = lit_decode_regs(r, lit, sub, matched, mb, lane);
+            } else
+#endif
             if (!st_is_char(state)) {
                 uint32_t mb = (uint64_t)rep0 < now ? uni(out[now - 1 - rep0]) : 0;
                 while (sym < 0x100) {
