@@ -334,7 +334,13 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     }
     (void)total;
     const unsigned in_flight = (unsigned)std::min<size_t>(nbatches, enc_streams);
-    const unsigned grid_cap = std::max(1u, resident / in_flight);
+    // Workgroups per launch: one per chunk up to this many.  For chunks of even size a launch has
+    // about resident / in_flight of them anyway; for many uneven ones, workgroups waiting in the
+    // dispatcher's queue balance the load better than resident ones looping over a fixed share.
+    // Each owns 140 KiB of HBM scratch (optimum table, literal models) per match-list slot.
+    unsigned grid_cap = 8192;
+    if ((uint64_t)grid_cap * lit_stride * sizeof(lz::prob_t) > lit_budget)
+        grid_cap = std::max(1u, (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t))));
     const unsigned max_grid = (unsigned)std::min<size_t>(max_chunks, grid_cap);
 
     int dev = 0;
