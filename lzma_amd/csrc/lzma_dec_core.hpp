@@ -6,8 +6,9 @@
 //
 // Execution model on the GPU: one 64-lane wavefront per stream.  Every lane
 // executes this code with identical (wave-uniform) values, so the compiler keeps
-// the range-coder state in scalar registers; probabilities live in LDS.  Only the
-// match copy and the model initialisation use the lanes in parallel.  On the host
+// the range-coder state in scalar registers; the non-literal probabilities live in LDS,
+// the literal ones in HBM (walked in registers, see below).  The match copy, the literal
+// model fetch and the model initialisation use the lanes in parallel.  On the host
 // (LZ_HOSTSIM) the same code runs with nlanes == 1.
 #pragma once
 #include "lzma_common.hpp"
