@@ -32,8 +32,10 @@ constexpr int32_t kPending = -1;
 
 // BIG == false: all streams; those with lc+lp > kLitSmallLog are
 // appended to big_list.  BIG == true: persistent grid over big_list.
+typedef __attribute__((address_space(3))) lz::prob_t lds_prob_t;
+
 template <bool BIG>
-__global__ __launch_bounds__(64) void decode_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decode_kernel(
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint64_t n_streams,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint32_t *big_count,
@@ -75,7 +77,12 @@ __global__ __launch_bounds__(64) void decode_kernel(
             for (uint32_t i = lane; i < lit_n / 2; i += 64) lw[i] = lz::kProbInit * 0x10001u;
         }
         __syncthreads();
-        const lz::DecodeResult r = lz::decode_stream<true>(sin, n, h, s_probs, lit, out + ob, oe - ob, lane, 64u);
+        // The model array as an LDS pointer held in a vector register the compiler cannot see
+        // through: model addresses are then formed on the vector unit, where LDS wants them,
+        // instead of on the scalar unit and copied over.
+        lds_prob_t *probs = (lds_prob_t *)s_probs;
+        asm volatile("" : "+v"(probs));
+        const lz::DecodeResult r = lz::decode_stream<true>(sin, n, h, probs, lit, out + ob, oe - ob, lane, 64u);
         if (lane == 0) {
             status[s] = r.status;
             out_sizes[s] = r.out_size;

@@ -34,18 +34,17 @@ struct RangeDec {
 };
 
 LZ_HD void rd_refill(RangeDec &r) {
-    uint64_t left = r.n - r.p;
-    if (left >= 8) {
-        uint64_t v;
-        __builtin_memcpy(&v, r.in + r.p, 8);
-        r.buf = v;
-        r.nbuf = 8;
-    } else {
-        uint64_t v = 0;
-        for (uint64_t i = 0; i < left; i++) v |= (uint64_t)r.in[r.p + i] << (8 * i);
-        r.buf = v;
-        r.nbuf = (uint32_t)left;
-    }
+    // The eight bytes that end with the last one wanted: near the end of the stream the load
+    // starts before `p` (never before the header, which is longer than eight bytes) and the
+    // bytes already consumed are shifted out.
+    const uint64_t left = r.n - r.p;
+    const uint32_t take = left < 8 ? (uint32_t)left : 8u;
+    uint64_t v;
+    __builtin_memcpy(&v, r.in + r.p + take - 8, 8);
+    // every lane loads the same bytes; saying so keeps the decoder state in scalar registers
+    v = (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
+    r.buf = take ? v >> (8 * (8 - take)) : 0;
+    r.nbuf = take;
 }
 LZ_HD uint32_t rd_byte(RangeDec &r) {
     if (r.nbuf == 0) {
@@ -67,25 +66,89 @@ LZ_HD void rd_normalize(RangeDec &r) {
         r.range <<= 8;
     }
 }
-// decodeBit, range_coder.go:75-105.
-template <class P>
-LZ_HD uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
-    uint32_t pr = uni(probs[idx]);
-    uint32_t bound = (r.range >> kProbBits) * pr;
-    uint32_t bit;
-    if (r.code < bound) {
-        r.range = bound;
-        probs[idx] = (prob_t)(pr + ((kProbTotal - pr) >> kMoveBits));
-        bit = 0;
-    } else {
-        r.range -= bound;
-        r.code -= bound;
-        probs[idx] = (prob_t)(pr - (pr >> kMoveBits));
-        bit = 1;
-    }
+// The arithmetic of decodeBit (range_coder.go:75-105) on a model value `pr`; returns the bit
+// and the updated model in `np`.  The update pr + ((2048 - pr) >> 5) of a zero bit equals
+// pr - ((pr - 2017) >> 5) with an arithmetic shift, which lets both outcomes share one
+// subtract-shift-subtract.
+LZ_HD uint32_t rd_step(RangeDec &r, uint32_t pr, uint32_t &np) {
+    const uint32_t bound = (r.range >> kProbBits) * pr;
+    const bool bit = r.code >= bound;
+    const uint32_t rb = r.range - bound, cb = r.code - bound;
+    r.range = bit ? rb : bound;
+    r.code = bit ? cb : r.code;
+    np = pr - (uint32_t)(((int32_t)pr - (bit ? 0 : (int32_t)(kProbTotal - (1u << kMoveBits) + 1))) >> kMoveBits);
+    rd_normalize(r);
+    return bit ? 1u : 0u;
+}
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+// On the GPU the decoder state is wave-uniform and a stream's speed is set by how many
+// instructions its wave issues, the scalar ones above all: a CU runs 32 such waves and its
+// scalar unit is the first to saturate.  The bit step is therefore written out by hand and
+// split between the two units: the interval arithmetic (one compare whose result drives
+// the selects, and the add-with-carry that shifts the bit into the symbol) on the scalar
+// unit, the model update on the vector unit, where every lane computes the same value.
+static_assert(kProbBits == 11 && kMoveBits == 5 && kProbTotal - (1u << kMoveBits) + 1 == 0x7e1, "constants in the asm");
+#define LZ_STEP_SCALAR                                  \
+    "s_lshr_b32 %[bound], %[range], 11\n\t"             \
+    "s_mul_i32 %[bound], %[bound], %[pr]\n\t"           \
+    "s_sub_u32 %[rb], %[range], %[bound]\n\t"           \
+    "s_sub_u32 %[cb], %[code], %[bound]\n\t"            \
+    "s_cmp_ge_u32 %[code], %[bound]\n\t"                \
+    "s_cselect_b32 %[range], %[rb], %[bound]\n\t"       \
+    "s_cselect_b32 %[code], %[cb], %[code]\n\t"         \
+    "s_cselect_b32 %[off], 0, 0x7e1\n\t"
+// `pv`: the model, the same value in every lane; `npv`: the updated model; k = 2k + bit
+LZ_D void rd_step_tree(RangeDec &r, uint32_t pv, uint32_t &npv, uint32_t &k) {
+    uint32_t pr, bound, rb, cb, off, range = uni(r.range), code = uni(r.code), kk = uni(k);
+    asm("v_readfirstlane_b32 %[pr], %[pv]\n\t" LZ_STEP_SCALAR
+        "s_addc_u32 %[k], %[k], %[k]\n\t"
+        "v_subrev_u32 %[npv], %[off], %[pv]\n\t"
+        "v_ashrrev_i32 %[npv], 5, %[npv]\n\t"
+        "v_sub_u32 %[npv], %[pv], %[npv]"
+        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off),
+          [npv] "=&v"(npv), [range] "+s"(range), [code] "+s"(code), [k] "+s"(kk)
+        : [pv] "v"(pv)
+        : "scc");
+    r.range = range;
+    r.code = code;
+    k = kk;
+    rd_normalize(r);
+}
+// the same, returning the bit
+LZ_D uint32_t rd_step_bit(RangeDec &r, uint32_t pv, uint32_t &npv) {
+    uint32_t pr, bound, rb, cb, off, bit, range = uni(r.range), code = uni(r.code);
+    asm("v_readfirstlane_b32 %[pr], %[pv]\n\t" LZ_STEP_SCALAR
+        "s_cselect_b32 %[bit], 1, 0\n\t"
+        "v_subrev_u32 %[npv], %[off], %[pv]\n\t"
+        "v_ashrrev_i32 %[npv], 5, %[npv]\n\t"
+        "v_sub_u32 %[npv], %[pv], %[npv]"
+        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off),
+          [npv] "=&v"(npv), [range] "+s"(range), [code] "+s"(code), [bit] "=&s"(bit)
+        : [pv] "v"(pv)
+        : "scc");
+    r.range = range;
+    r.code = code;
     rd_normalize(r);
     return bit;
 }
+// decodeBit, range_coder.go:75-105.
+template <class P>
+LZ_D uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
+    uint32_t np;
+    const uint32_t bit = rd_step_bit(r, probs[idx], np);
+    probs[idx] = (prob_t)np;
+    return bit;
+}
+#else
+// decodeBit, range_coder.go:75-105.
+template <class P>
+LZ_HD uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
+    uint32_t np;
+    const uint32_t bit = rd_step(r, probs[idx], np);
+    probs[idx] = (prob_t)np;
+    return bit;
+}
+#endif
 // decodeDirectBits, range_coder.go:57-73.
 LZ_HD uint32_t rd_direct(RangeDec &r, uint32_t nbits) {
     uint32_t res = 0;
@@ -99,6 +162,30 @@ LZ_HD uint32_t rd_direct(RangeDec &r, uint32_t nbits) {
     return res;
 }
 // rangeBitTreeCoder.decode / reverseDecode, range_bit_tree_coder.go:19-51.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+template <class P>
+LZ_D uint32_t bt_walk(RangeDec &r, P *probs, uint32_t nbits) {  // node index after nbits steps from the root
+    uint32_t k = 1;
+    for (uint32_t i = nbits; i != 0; i--) {
+        uint32_t np;
+        P *m = probs + k;
+        rd_step_tree(r, *m, np, k);
+        *m = (prob_t)np;
+    }
+    return k;
+}
+template <class P>
+LZ_D uint32_t bt_decode(RangeDec &r, P *probs, uint32_t base, uint32_t nbits) {
+    return bt_walk(r, probs + base, nbits) - (1u << nbits);
+}
+template <class P>
+LZ_D uint32_t bt_rev_decode(RangeDec &r, P *probs, uint32_t base, uint32_t nbits) {
+    // the walk visits the same nodes as the forward tree; its bits, shifted in first-decoded-highest,
+    // are wanted lowest first
+    const uint32_t k = bt_walk(r, probs + base, nbits);
+    return (__builtin_bitreverse32(k) >> (32 - nbits)) & ((1u << nbits) - 1);
+}
+#else
 template <class P>
 LZ_HD uint32_t bt_decode(RangeDec &r, P *probs, uint32_t base, uint32_t nbits) {
     uint32_t k = 1;
@@ -115,78 +202,133 @@ LZ_HD uint32_t bt_rev_decode(RangeDec &r, P *probs, uint32_t base, uint32_t nbit
     }
     return res;
 }
+#endif
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 // ---- literal coder walked in registers (GPU only)
 // The literal models are too large to keep every stream's in LDS without giving up most
 // of the streams a CU could hold, and decoding a literal from models in HBM one bit at a
 // time would cost a memory round trip per bit.  Instead the 256 models of a literal bit
-// tree are fetched at once, two 16-bit models per 32-bit word, word j of the tree in lane
-// j and word j + 64 in a second register; the walk picks each model out of the lanes with
-// a readlane, the lane that holds it keeps the updated value, and the words that changed
-// are stored back when the symbol is complete.
-struct TreeW {
-    uint32_t w0, w1;
-    bool d0, d1;  // this lane's word was updated
+// tree are fetched at once into four registers, model k in lane k & 63 of register k >> 6.
+// Bits 1..6 of a symbol use nodes 1..63 (register 0), bit 7 nodes 64..127 (register 1) and
+// bit 8 nodes 128..255 (registers 2 and 3), so the register is known when the code is
+// compiled.  A bit costs one readlane to fetch the model; every lane then updates its own
+// model as if it had been the one read, and the lane that holds it keeps the result.
+struct Tree4 {
+    uint32_t r0, r1, r2, r3;
 };
-// the models base .. base + 255 (node k of the tree is model base + k); base is even
+// the models base .. base + 255 (node k of the tree is model base + k)
 template <class L>
-LZ_D TreeW tree_load(const L *lit, uint32_t base, uint32_t lane) {
-    const uint32_t *wp = (const uint32_t *)(lit + base);
-    TreeW t;
-    t.w0 = wp[lane];
-    t.w1 = wp[lane + 64];
-    t.d0 = t.d1 = false;
+LZ_D Tree4 tree_load(const L *lit, uint32_t base, uint32_t lane) {
+    const L *p = lit + base + lane;
+    Tree4 t;
+    t.r0 = p[0];
+    t.r1 = p[64];
+    t.r2 = p[128];
+    t.r3 = p[192];
     return t;
 }
 template <class L>
-LZ_D void tree_store(L *lit, uint32_t base, uint32_t lane, const TreeW &t) {
-    uint32_t *wp = (uint32_t *)(lit + base);
-    if (t.d0) wp[lane] = t.w0;
-    if (t.d1) wp[lane + 64] = t.w1;
+LZ_D void tree_store(L *lit, uint32_t base, uint32_t lane, const Tree4 &t) {
+    L *p = lit + base + lane;
+    p[0] = (L)t.r0;
+    p[64] = (L)t.r1;
+    p[128] = (L)t.r2;
+    p[192] = (L)t.r3;
 }
-// decodeBit (range_coder.go:75-105) on node k of a loaded tree
-LZ_D uint32_t tree_bit(RangeDec &r, TreeW &t, uint32_t k, uint32_t lane) {
-    const uint32_t word = k >> 1, src = word & 63u, sh = (k & 1u) << 4;
-    const bool second = word >= 64;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)(second ? t.w1 : t.w0), (int)src);
-    const uint32_t pr = (w >> sh) & 0xFFFFu;
-    const uint32_t bound = (r.range >> kProbBits) * pr;
-    uint32_t bit, np;
-    if (r.code < bound) {
-        r.range = bound;
-        np = pr + ((kProbTotal - pr) >> kMoveBits);
-        bit = 0;
-    } else {
-        r.range -= bound;
-        r.code -= bound;
-        np = pr - (pr >> kMoveBits);
-        bit = 1;
-    }
-    const uint32_t nw = (w & ~(0xFFFFu << sh)) | (np << sh);
-    if (lane == src) {
-        if (second) t.w1 = nw, t.d1 = true; else t.w0 = nw, t.d0 = true;
-    }
+// decodeBit (range_coder.go:75-105) on node `sym` of a tree: `reg` is the register that holds
+// the node, `node_of_lane` the node each lane of it holds; sym = 2 sym + bit.
+// (v_readlane takes the lane from the low six bits of sym.  The compiler does not look inside
+// the block, so the block itself keeps the distance the hardware wants between a vector
+// instruction that writes `sym` or `reg` just before it and the readlane that uses them.)
+LZ_D void lit_step(RangeDec &r, uint32_t &reg, uint32_t node_of_lane, uint32_t &sym) {
+    uint32_t pr, bound, rb, cb, off, t, range = uni(r.range), code = uni(r.code), s = uni(sym);
+    asm("s_nop 3\n\t"
+        "v_readlane_b32 %[pr], %[reg], %[sym]\n\t"
+        "v_cmp_eq_u32 vcc, %[sym], %[node]\n\t" LZ_STEP_SCALAR
+        "v_subrev_u32 %[t], %[off], %[reg]\n\t"
+        "v_ashrrev_i32 %[t], 5, %[t]\n\t"
+        "v_sub_u32 %[t], %[reg], %[t]\n\t"
+        "v_cndmask_b32 %[reg], %[reg], %[t], vcc\n\t"
+        "s_addc_u32 %[sym], %[sym], %[sym]"
+        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [t] "=&v"(t),
+          [reg] "+v"(reg), [range] "+s"(range), [code] "+s"(code), [sym] "+s"(s)
+        : [node] "v"(node_of_lane)
+        : "scc", "vcc");
+    r.range = range;
+    r.code = code;
+    sym = s;
     rd_normalize(r);
-    return bit;
 }
-// litSubCoder.decodeNormal / decodeWithMatchByte, lzma_lit_coder.go:18-44
+// bit number I (0 = first) of a symbol whose bits so far are `sym` (with the leading one)
+template <int I>
+LZ_D void tree_bit(RangeDec &r, Tree4 &t, uint32_t &sym, uint32_t lane) {
+    if (I < 6) lit_step(r, t.r0, lane, sym);
+    else if (I == 6) lit_step(r, t.r1, lane + 64, sym);
+    else if (sym & 64u) lit_step(r, t.r3, lane + 192, sym);
+    else lit_step(r, t.r2, lane + 128, sym);
+}
+// litSubCoder.decodeNormal / decodeWithMatchByte, lzma_lit_coder.go:18-44.  After a match the
+// tree is chosen by the next bit of the byte the match would have continued with, for as long
+// as the decoded bits agree with it (LZ_MATCHED); from the first difference on, and for every
+// bit of an ordinary literal, it is the plain tree.  The two match-byte trees are fetched only
+// as far as the walk gets: their first six levels at the start, the last two when bit 7 is
+// reached with all bits so far in agreement.
 template <class L>
 LZ_D uint32_t lit_decode_regs(RangeDec &r, L *lit, uint32_t sub, bool matched, uint32_t mb, uint32_t lane) {
-    TreeW a = tree_load(lit, sub, lane);
+    Tree4 a = tree_load(lit, sub, lane);
     uint32_t sym = 1;
     if (matched) {
-        TreeW b0 = tree_load(lit, sub + 0x100u, lane), b1 = tree_load(lit, sub + 0x200u, lane);
-        while (sym < 0x100) {
-            const uint32_t mbit = (mb >> 7) & 1;
-            mb <<= 1;
-            const uint32_t b = mbit ? tree_bit(r, b1, sym, lane) : tree_bit(r, b0, sym, lane);
-            sym = (sym << 1) | b;
-            if (mbit != b) break;
-        }
-        tree_store(lit, sub + 0x100u, lane, b0);
-        tree_store(lit, sub + 0x200u, lane, b1);
+        L *p0 = lit + sub + 0x100u + lane, *p1 = lit + sub + 0x200u + lane;
+        Tree4 b0, b1;
+        b0.r0 = p0[0];
+        b1.r0 = p1[0];
+#define LZ_MATCHED(I, NEXT)                    \
+    if (mb & (0x80u >> I)) {                   \
+        tree_bit<I>(r, b1, sym, lane);         \
+        if (!(sym & 1u)) goto NEXT;            \
+    } else {                                   \
+        tree_bit<I>(r, b0, sym, lane);         \
+        if (sym & 1u) goto NEXT;               \
     }
-    while (sym < 0x100) sym = (sym << 1) | tree_bit(r, a, sym, lane);
+        LZ_MATCHED(0, m1)
+        LZ_MATCHED(1, m2)
+        LZ_MATCHED(2, m3)
+        LZ_MATCHED(3, m4)
+        LZ_MATCHED(4, m5)
+        LZ_MATCHED(5, m6)
+        b0.r1 = p0[64], b0.r2 = p0[128], b0.r3 = p0[192];
+        b1.r1 = p1[64], b1.r2 = p1[128], b1.r3 = p1[192];
+        {
+            bool plain7 = true;
+            LZ_MATCHED(6, deep)
+            plain7 = false;
+            LZ_MATCHED(7, deep)
+        deep:
+            p0[64] = (L)b0.r1, p0[128] = (L)b0.r2, p0[192] = (L)b0.r3;
+            p1[64] = (L)b1.r1, p1[128] = (L)b1.r2, p1[192] = (L)b1.r3;
+            if (plain7) goto m7;
+            goto m8;
+        }
+#undef LZ_MATCHED
+    m1: tree_bit<1>(r, a, sym, lane);
+    m2: tree_bit<2>(r, a, sym, lane);
+    m3: tree_bit<3>(r, a, sym, lane);
+    m4: tree_bit<4>(r, a, sym, lane);
+    m5: tree_bit<5>(r, a, sym, lane);
+    m6: tree_bit<6>(r, a, sym, lane);
+    m7: tree_bit<7>(r, a, sym, lane);
+    m8: p0[0] = (L)b0.r0;
+        p1[0] = (L)b1.r0;
+    } else {
+        tree_bit<0>(r, a, sym, lane);
+        tree_bit<1>(r, a, sym, lane);
+        tree_bit<2>(r, a, sym, lane);
+        tree_bit<3>(r, a, sym, lane);
+        tree_bit<4>(r, a, sym, lane);
+        tree_bit<5>(r, a, sym, lane);
+        tree_bit<6>(r, a, sym, lane);
+        tree_bit<7>(r, a, sym, lane);
+    }
     tree_store(lit, sub, lane, a);
     return sym;
 }
