@@ -21,43 +21,49 @@ LZ_D uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(
 LZ_HD uint32_t uni(uint32_t v) { return v; }
 #endif
 
-// Range decoder state (rangeDecoder, range_coder.go:27-31).  Input bytes are
-// fetched eight at a time; `p` is the offset of the next unread byte.
+// Range decoder state (rangeDecoder, range_coder.go:27-31).  Input bytes are fetched seven
+// at a time into `win`, the next byte in its top eight bits; a single set bit below the
+// unread bytes marks their end, so the window is empty when only that bit is left.
 struct RangeDec {
     const uint8_t *in;
-    uint64_t n;   // stream length in bytes
-    uint64_t p;   // next byte to hand out
-    uint64_t buf; // up to 8 prefetched bytes, next byte in the low 8 bits
-    uint32_t nbuf;
+    uint64_t n;    // stream length in bytes
+    uint64_t p;    // offset of the first byte not yet in the window
+    uint64_t win;  // unread bytes, first one on top, then the marker bit
     uint32_t range, code;
     uint32_t eof;  // set once a read past the end was attempted
 };
+constexpr uint64_t kWinEmpty = 1ull << 63;
 
 LZ_HD void rd_refill(RangeDec &r) {
     // The eight bytes that end with the last one wanted: near the end of the stream the load
     // starts before `p` (never before the header, which is longer than eight bytes) and the
-    // bytes already consumed are shifted out.
+    // bytes already consumed are shifted out.  Past the end the window delivers zeros.
     const uint64_t left = r.n - r.p;
-    const uint32_t take = left < 8 ? (uint32_t)left : 8u;
-    uint64_t v;
-    __builtin_memcpy(&v, r.in + r.p + take - 8, 8);
-    // every lane loads the same bytes; saying so keeps the decoder state in scalar registers
-    v = (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
-    r.buf = take ? v >> (8 * (8 - take)) : 0;
-    r.nbuf = take;
+    const uint32_t take = left < 7 ? (uint32_t)left : 7u;
+    uint64_t v = 0;
+    if (take) {
+        __builtin_memcpy(&v, r.in + r.p + take - 8, 8);
+        v = __builtin_bswap64(v);
+        // every lane loads the same bytes; saying so keeps the decoder state in scalar registers
+        v = (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
+        v <<= 8 * (8 - take);
+        r.p += take;
+        r.win = v | (0x80ull << (8 * (7 - take)));
+    } else {
+        r.eof = 1;
+        r.win = 0x80;
+    }
 }
 LZ_HD uint32_t rd_byte(RangeDec &r) {
-    if (r.nbuf == 0) {
-        rd_refill(r);
-        if (r.nbuf == 0) {
-            r.eof = 1;
-            return 0;
-        }
-    }
-    uint32_t b = (uint32_t)r.buf & 0xFF;
-    r.buf >>= 8;
-    r.nbuf--;
-    r.p++;
+    if (r.win == kWinEmpty) rd_refill(r);
+    uint32_t b = (uint32_t)(r.win >> 56);
+    r.win <<= 8;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    // Keeps the byte a value of its own: merged with the caller's shift of `code` it would
+    // become a funnel shift, which only the vector unit has.
+    b = uni(b);
+    asm("" : "+s"(b));
+#endif
     return b;
 }
 LZ_HD void rd_normalize(RangeDec &r) {
@@ -83,60 +89,57 @@ LZ_HD uint32_t rd_step(RangeDec &r, uint32_t pr, uint32_t &np) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 // On the GPU the decoder state is wave-uniform and a stream's speed is set by how many
 // instructions its wave issues, the scalar ones above all: a CU runs 32 such waves and its
-// scalar unit is the first to saturate.  The bit step is therefore written out by hand and
-// split between the two units: the interval arithmetic (one compare whose result drives
-// the selects, and the add-with-carry that shifts the bit into the symbol) on the scalar
-// unit, the model update on the vector unit, where every lane computes the same value.
+// scalar unit is the first to saturate.  The bit step is therefore split between the two
+// units.  The interval arithmetic runs on the scalar unit and is written out by hand, eight
+// instructions: the unsigned minimum of code and code - bound is the new code and leaves
+// the decoded bit in SCC, which drives the selects and the add-with-carry that shifts the
+// bit into the symbol.  The model update runs on the vector unit, every lane computing the
+// same value, from the model as loaded and the scalar `off` (0 or 2017).
 static_assert(kProbBits == 11 && kMoveBits == 5 && kProbTotal - (1u << kMoveBits) + 1 == 0x7e1, "constants in the asm");
 #define LZ_STEP_SCALAR                                  \
     "s_lshr_b32 %[bound], %[range], 11\n\t"             \
     "s_mul_i32 %[bound], %[bound], %[pr]\n\t"           \
     "s_sub_u32 %[rb], %[range], %[bound]\n\t"           \
     "s_sub_u32 %[cb], %[code], %[bound]\n\t"            \
-    "s_cmp_ge_u32 %[code], %[bound]\n\t"                \
+    "s_min_u32 %[code], %[cb], %[code]\n\t"             \
     "s_cselect_b32 %[range], %[rb], %[bound]\n\t"       \
-    "s_cselect_b32 %[code], %[cb], %[code]\n\t"         \
     "s_cselect_b32 %[off], 0, 0x7e1\n\t"
-// `pv`: the model, the same value in every lane; `npv`: the updated model; k = 2k + bit
-LZ_D void rd_step_tree(RangeDec &r, uint32_t pv, uint32_t &npv, uint32_t &k) {
-    uint32_t pr, bound, rb, cb, off, range = uni(r.range), code = uni(r.code), kk = uni(k);
-    asm("v_readfirstlane_b32 %[pr], %[pv]\n\t" LZ_STEP_SCALAR
-        "s_addc_u32 %[k], %[k], %[k]\n\t"
-        "v_subrev_u32 %[npv], %[off], %[pv]\n\t"
-        "v_ashrrev_i32 %[npv], 5, %[npv]\n\t"
-        "v_sub_u32 %[npv], %[pv], %[npv]"
-        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off),
-          [npv] "=&v"(npv), [range] "+s"(range), [code] "+s"(code), [k] "+s"(kk)
-        : [pv] "v"(pv)
+// k = 2k + bit; returns off
+LZ_D uint32_t rd_step_tree(RangeDec &r, uint32_t pr, uint32_t &k) {
+    // (uni() costs nothing on a value already in a scalar register and keeps the build from
+    // failing where the compiler chose a vector register for one)
+    uint32_t bound, rb, cb, off, range = uni(r.range), code = uni(r.code), kk = uni(k);
+    asm(LZ_STEP_SCALAR "s_addc_u32 %[k], %[k], %[k]"
+        : [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [range] "+s"(range),
+          [code] "+s"(code), [k] "+s"(kk)
+        : [pr] "s"(pr)
         : "scc");
-    r.range = range;
-    r.code = code;
-    k = kk;
-    rd_normalize(r);
+    r.range = range, r.code = code, k = kk;
+    return off;
 }
-// the same, returning the bit
-LZ_D uint32_t rd_step_bit(RangeDec &r, uint32_t pv, uint32_t &npv) {
-    uint32_t pr, bound, rb, cb, off, bit, range = uni(r.range), code = uni(r.code);
-    asm("v_readfirstlane_b32 %[pr], %[pv]\n\t" LZ_STEP_SCALAR
-        "s_cselect_b32 %[bit], 1, 0\n\t"
-        "v_subrev_u32 %[npv], %[off], %[pv]\n\t"
-        "v_ashrrev_i32 %[npv], 5, %[npv]\n\t"
-        "v_sub_u32 %[npv], %[pv], %[npv]"
-        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off),
-          [npv] "=&v"(npv), [range] "+s"(range), [code] "+s"(code), [bit] "=&s"(bit)
-        : [pv] "v"(pv)
+// the same, handing out the bit
+LZ_D uint32_t rd_step_bit(RangeDec &r, uint32_t pr, uint32_t &bit) {
+    uint32_t bound, rb, cb, off, range = uni(r.range), code = uni(r.code);
+    asm(LZ_STEP_SCALAR "s_cselect_b32 %[bit], 1, 0"
+        : [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [range] "+s"(range),
+          [code] "+s"(code), [bit] "=&s"(bit)
+        : [pr] "s"(pr)
         : "scc");
-    r.range = range;
-    r.code = code;
-    rd_normalize(r);
-    return bit;
+    r.range = range, r.code = code;
+    return off;
+}
+// the model update, on a value every lane holds
+LZ_D uint32_t model_update(uint32_t pv, uint32_t off) {
+    return pv - (uint32_t)((int32_t)(pv - off) >> kMoveBits);
 }
 // decodeBit, range_coder.go:75-105.
 template <class P>
 LZ_D uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
-    uint32_t np;
-    const uint32_t bit = rd_step_bit(r, probs[idx], np);
-    probs[idx] = (prob_t)np;
+    const uint32_t pv = probs[idx];
+    uint32_t bit;
+    const uint32_t off = rd_step_bit(r, uni(pv), bit);
+    probs[idx] = (prob_t)model_update(pv, off);
+    rd_normalize(r);
     return bit;
 }
 #else
@@ -153,10 +156,23 @@ LZ_HD uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
 LZ_HD uint32_t rd_direct(RangeDec &r, uint32_t nbits) {
     uint32_t res = 0;
     for (uint32_t i = nbits; i != 0; i--) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        uint32_t cb, range = uni(r.range), code = uni(r.code);  // the minimum leaves the bit in SCC, as above
+        res = uni(res);
+        asm("s_lshr_b32 %[range], %[range], 1\n\t"
+            "s_sub_u32 %[cb], %[code], %[range]\n\t"
+            "s_min_u32 %[code], %[cb], %[code]\n\t"
+            "s_addc_u32 %[res], %[res], %[res]"
+            : [cb] "=&s"(cb), [range] "+s"(range), [code] "+s"(code), [res] "+s"(res)
+            :
+            : "scc");
+        r.range = range, r.code = code;
+#else
         r.range >>= 1;
         uint32_t t = (r.code - r.range) >> 31;
         r.code -= r.range & (t - 1);
         res = (res << 1) | (1 - t);
+#endif
         rd_normalize(r);
     }
     return res;
@@ -167,10 +183,11 @@ template <class P>
 LZ_D uint32_t bt_walk(RangeDec &r, P *probs, uint32_t nbits) {  // node index after nbits steps from the root
     uint32_t k = 1;
     for (uint32_t i = nbits; i != 0; i--) {
-        uint32_t np;
         P *m = probs + k;
-        rd_step_tree(r, *m, np, k);
-        *m = (prob_t)np;
+        const uint32_t pv = *m;
+        const uint32_t off = rd_step_tree(r, uni(pv), k);
+        *m = (prob_t)model_update(pv, off);
+        rd_normalize(r);
     }
     return k;
 }
@@ -236,36 +253,23 @@ LZ_D void tree_store(L *lit, uint32_t base, uint32_t lane, const Tree4 &t) {
     p[192] = (L)t.r3;
 }
 // decodeBit (range_coder.go:75-105) on node `sym` of a tree: `reg` is the register that holds
-// the node, `node_of_lane` the node each lane of it holds; sym = 2 sym + bit.
-// (v_readlane takes the lane from the low six bits of sym.  The compiler does not look inside
-// the block, so the block itself keeps the distance the hardware wants between a vector
-// instruction that writes `sym` or `reg` just before it and the readlane that uses them.)
-LZ_D void lit_step(RangeDec &r, uint32_t &reg, uint32_t node_of_lane, uint32_t &sym) {
-    uint32_t pr, bound, rb, cb, off, t, range = uni(r.range), code = uni(r.code), s = uni(sym);
-    asm("s_nop 3\n\t"
-        "v_readlane_b32 %[pr], %[reg], %[sym]\n\t"
-        "v_cmp_eq_u32 vcc, %[sym], %[node]\n\t" LZ_STEP_SCALAR
-        "v_subrev_u32 %[t], %[off], %[reg]\n\t"
-        "v_ashrrev_i32 %[t], 5, %[t]\n\t"
-        "v_sub_u32 %[t], %[reg], %[t]\n\t"
-        "v_cndmask_b32 %[reg], %[reg], %[t], vcc\n\t"
-        "s_addc_u32 %[sym], %[sym], %[sym]"
-        : [pr] "=&s"(pr), [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [t] "=&v"(t),
-          [reg] "+v"(reg), [range] "+s"(range), [code] "+s"(code), [sym] "+s"(s)
-        : [node] "v"(node_of_lane)
-        : "scc", "vcc");
-    r.range = range;
-    r.code = code;
-    sym = s;
+// the node, `node2_of_lane` twice the node each lane of it holds; sym = 2 sym + bit.
+// (v_readlane takes the lane from the low six bits of sym.)
+LZ_D void lit_step(RangeDec &r, uint32_t &reg, uint32_t node2_of_lane, uint32_t &sym) {
+    const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)sym);
+    const uint32_t off = rd_step_tree(r, pr, sym);
+    const uint32_t np = model_update(reg, off);
+    // the lane whose node was read: node == sym >> 1, tested on the vector unit
+    reg = sym - node2_of_lane < 2u ? np : reg;
     rd_normalize(r);
 }
 // bit number I (0 = first) of a symbol whose bits so far are `sym` (with the leading one)
 template <int I>
 LZ_D void tree_bit(RangeDec &r, Tree4 &t, uint32_t &sym, uint32_t lane) {
-    if (I < 6) lit_step(r, t.r0, lane, sym);
-    else if (I == 6) lit_step(r, t.r1, lane + 64, sym);
-    else if (sym & 64u) lit_step(r, t.r3, lane + 192, sym);
-    else lit_step(r, t.r2, lane + 128, sym);
+    if (I < 6) lit_step(r, t.r0, 2 * lane, sym);
+    else if (I == 6) lit_step(r, t.r1, 2 * lane + 128, sym);
+    else if (sym & 64u) lit_step(r, t.r3, 2 * lane + 384, sym);
+    else lit_step(r, t.r2, 2 * lane + 256, sym);
 }
 // litSubCoder.decodeNormal / decodeWithMatchByte, lzma_lit_coder.go:18-44.  After a match the
 // tree is chosen by the next bit of the byte the match would have continued with, for as long
@@ -370,8 +374,7 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
     r.in = in;
     r.n = n;
     r.p = kHeaderSize;
-    r.buf = 0;
-    r.nbuf = 0;
+    r.win = kWinEmpty;
     r.range = 0xFFFFFFFFu;
     r.code = 0;
     r.eof = 0;
