@@ -31,6 +31,7 @@ struct RangeDec {
     uint64_t win;  // unread bytes, first one on top, then the marker bit
     uint32_t range, code;
     uint32_t eof;  // set once a read past the end was attempted
+    uint32_t lim;  // the output position may grow up to here; zero once eof is set
 };
 constexpr uint64_t kWinEmpty = 1ull << 63;
 
@@ -51,6 +52,7 @@ LZ_HD void rd_refill(RangeDec &r) {
         r.win = v | (0x80ull << (8 * (7 - take)));
     } else {
         r.eof = 1;
+        r.lim = 0;
         r.win = 0x80;
     }
 }
@@ -89,56 +91,58 @@ LZ_HD uint32_t rd_step(RangeDec &r, uint32_t pr, uint32_t &np) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 // On the GPU the decoder state is wave-uniform and a stream's speed is set by how many
 // instructions its wave issues, the scalar ones above all: a CU runs 32 such waves and its
-// scalar unit is the first to saturate.  The bit step is therefore split between the two
-// units.  The interval arithmetic runs on the scalar unit and is written out by hand, eight
-// instructions: the unsigned minimum of code and code - bound is the new code and leaves
-// the decoded bit in SCC, which drives the selects and the add-with-carry that shifts the
-// bit into the symbol.  The model update runs on the vector unit, every lane computing the
-// same value, from the model as loaded and the scalar `off` (0 or 2017).
-static_assert(kProbBits == 11 && kMoveBits == 5 && kProbTotal - (1u << kMoveBits) + 1 == 0x7e1, "constants in the asm");
+// scalar unit is the first to saturate, the vector unit the second.  The bit step is
+// therefore split between the two.  Vector unit: bound = (range >> 11) * model, computed
+// where the model is (every lane holds the same one, or in the literal trees each lane its
+// own); the model update, from the decoded bit.  Scalar unit, written out by hand: the
+// unsigned minimum of code and code - bound is the new code and leaves the decoded bit in
+// SCC, which drives the select of the new range and the add-with-carry that shifts the bit
+// into the symbol.
+static_assert(kProbBits == 11 && kMoveBits == 5 && kProbTotal == 2048, "constants of the bit step");
 #define LZ_STEP_SCALAR                                  \
-    "s_lshr_b32 %[bound], %[range], 11\n\t"             \
-    "s_mul_i32 %[bound], %[bound], %[pr]\n\t"           \
     "s_sub_u32 %[rb], %[range], %[bound]\n\t"           \
     "s_sub_u32 %[cb], %[code], %[bound]\n\t"            \
     "s_min_u32 %[code], %[cb], %[code]\n\t"             \
-    "s_cselect_b32 %[range], %[rb], %[bound]\n\t"       \
-    "s_cselect_b32 %[off], 0, 0x7e1\n\t"
-// k = 2k + bit; returns off
-LZ_D uint32_t rd_step_tree(RangeDec &r, uint32_t pr, uint32_t &k) {
+    "s_cselect_b32 %[range], %[rb], %[bound]\n\t"
+// k = 2k + bit
+LZ_D void rd_step_tree(RangeDec &r, uint32_t bound, uint32_t &k) {
     // (uni() costs nothing on a value already in a scalar register and keeps the build from
     // failing where the compiler chose a vector register for one)
-    uint32_t bound, rb, cb, off, range = uni(r.range), code = uni(r.code), kk = uni(k);
+    uint32_t rb, cb, range = uni(r.range), code = uni(r.code), kk = uni(k);
     asm(LZ_STEP_SCALAR "s_addc_u32 %[k], %[k], %[k]"
-        : [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [range] "+s"(range),
-          [code] "+s"(code), [k] "+s"(kk)
-        : [pr] "s"(pr)
+        : [rb] "=&s"(rb), [cb] "=&s"(cb), [range] "+s"(range), [code] "+s"(code), [k] "+s"(kk)
+        : [bound] "s"(bound)
         : "scc");
     r.range = range, r.code = code, k = kk;
-    return off;
 }
 // the same, handing out the bit
-LZ_D uint32_t rd_step_bit(RangeDec &r, uint32_t pr, uint32_t &bit) {
-    uint32_t bound, rb, cb, off, range = uni(r.range), code = uni(r.code);
+LZ_D uint32_t rd_step_bit(RangeDec &r, uint32_t bound) {
+    uint32_t rb, cb, bit, range = uni(r.range), code = uni(r.code);
     asm(LZ_STEP_SCALAR "s_cselect_b32 %[bit], 1, 0"
-        : [bound] "=&s"(bound), [rb] "=&s"(rb), [cb] "=&s"(cb), [off] "=&s"(off), [range] "+s"(range),
-          [code] "+s"(code), [bit] "=&s"(bit)
-        : [pr] "s"(pr)
+        : [rb] "=&s"(rb), [cb] "=&s"(cb), [range] "+s"(range), [code] "+s"(code), [bit] "=&s"(bit)
+        : [bound] "s"(bound)
         : "scc");
     r.range = range, r.code = code;
-    return off;
+    return bit;
 }
-// the model update, on a value every lane holds
-LZ_D uint32_t model_update(uint32_t pv, uint32_t off) {
-    return pv - (uint32_t)((int32_t)(pv - off) >> kMoveBits);
+// bound of a model held in a vector register
+LZ_D uint32_t model_bound(const RangeDec &r, uint32_t pv) {
+    return __umul24(pv, r.range >> kProbBits);  // 11 x 21 bits
+}
+// The model update on the vector unit; `bits` is a scalar whose lowest bit is the decoded one.
+// pv + ((2048 - pv) >> 5) for a zero equals pv - ((pv - 2017) >> 5) with an arithmetic shift,
+// so both cases are pv - ((pv - off) >> 5) with off = 2017 or 0.
+LZ_D uint32_t model_update(uint32_t pv, uint32_t bits) {
+    uint32_t m;  // all ones for a one bit; on the vector unit on purpose
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "s"(bits));
+    return pv - (uint32_t)((int32_t)(pv - (kProbTotal - 31u) + (m & (kProbTotal - 31u))) >> kMoveBits);
 }
 // decodeBit, range_coder.go:75-105.
 template <class P>
 LZ_D uint32_t rd_bit(RangeDec &r, P *probs, uint32_t idx) {
     const uint32_t pv = probs[idx];
-    uint32_t bit;
-    const uint32_t off = rd_step_bit(r, uni(pv), bit);
-    probs[idx] = (prob_t)model_update(pv, off);
+    const uint32_t bit = rd_step_bit(r, uni(model_bound(r, pv)));
+    probs[idx] = (prob_t)model_update(pv, bit);
     rd_normalize(r);
     return bit;
 }
@@ -185,8 +189,8 @@ LZ_D uint32_t bt_walk(RangeDec &r, P *probs, uint32_t nbits) {  // node index af
     for (uint32_t i = nbits; i != 0; i--) {
         P *m = probs + k;
         const uint32_t pv = *m;
-        const uint32_t off = rd_step_tree(r, uni(pv), k);
-        *m = (prob_t)model_update(pv, off);
+        rd_step_tree(r, uni(model_bound(r, pv)), k);
+        *m = (prob_t)model_update(pv, k);
         rd_normalize(r);
     }
     return k;
@@ -256,9 +260,10 @@ LZ_D void tree_store(L *lit, uint32_t base, uint32_t lane, const Tree4 &t) {
 // the node, `node2_of_lane` twice the node each lane of it holds; sym = 2 sym + bit.
 // (v_readlane takes the lane from the low six bits of sym.)
 LZ_D void lit_step(RangeDec &r, uint32_t &reg, uint32_t node2_of_lane, uint32_t &sym) {
-    const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)sym);
-    const uint32_t off = rd_step_tree(r, pr, sym);
-    const uint32_t np = model_update(reg, off);
+    // every lane forms the bound of its own model; the one of node `sym` is taken
+    const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)model_bound(r, reg), (int)sym);
+    rd_step_tree(r, bound, sym);
+    const uint32_t np = model_update(reg, sym);
     // the lane whose node was read: node == sym >> 1, tested on the vector unit
     reg = sym - node2_of_lane < 2u ? np : reg;
     rd_normalize(r);
@@ -353,6 +358,10 @@ struct DecodeResult {
     uint64_t out_size;
 };
 
+// The output position is kept in 32 bits: a stream may produce at most this many bytes
+// (more ends with ST_OUT_CAP).  Leaves room for position + longest match without overflow.
+constexpr uint32_t kMaxStreamOut = 0xFFFFFE00u;
+
 // Decodes one stream.  `probs` holds kNumBaseProbs models followed (when
 // lit == probs + P_LIT) by the literal coder; `lit` may also point to a separate
 // array.  All models must already be initialised to kProbInit.
@@ -378,32 +387,35 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
     r.range = 0xFFFFFFFFu;
     r.code = 0;
     r.eof = 0;
+    // Output may grow up to `lim`.  Running out of input sets it to zero (rd_refill), so the one
+    // test made before a symbol is written also catches a truncated stream, where the
+    // reference stops with the symbols decoded so far (range_coder.go:82-85).
+    r.lim = out_cap < kMaxStreamOut ? (uint32_t)out_cap : kMaxStreamOut;
     for (int i = 0; i < 5; i++) r.code = (r.code << 8) | rd_byte(r);
 
     const uint32_t dict_check = h.dict_size > 1 ? h.dict_size : 1;
     const uint32_t ps_mask = (1u << h.pb) - 1, lp_mask = (1u << h.lp) - 1, lc = h.lc;
     const int64_t unpack = h.unpack_size;
+    const uint32_t end = unpack < 0 || unpack > (int64_t)kMaxStreamOut ? kMaxStreamOut : (uint32_t)unpack;
     uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
-    uint64_t now = 0;
+    uint32_t now = 0;
     uint32_t prev = 0;
+    uint32_t match_byte = 0;  // the byte the last match would have continued with
     int32_t status = ST_OK;
 
-    while (unpack < 0 || (int64_t)now < unpack) {
-        uint32_t ps = (uint32_t)now & ps_mask;
+    while (now < end) {
+        uint32_t ps = now & ps_mask;
         if (rd_bit(r, probs, P_IS_MATCH + (state << kPosStatesBitsMax) + ps) == 0) {
             // litCoder.getSubCoder, lzma_lit_coder.go:126-128
-            uint32_t sub = ((((uint32_t)now & lp_mask) << lc) + (prev >> (8 - lc))) * 0x300u;
+            uint32_t sub = (((now & lp_mask) << lc) + (prev >> (8 - lc))) * 0x300u;
             uint32_t sym = 1;
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
             if (LIT_REGS) {
-                const bool matched = !st_is_char(state);
-                uint32_t mb = 0;
-                if (matched && (uint64_t)rep0 < now) mb = uni(out[now - 1 - rep0]);
-                sym = lit_decode_regs(r, lit, sub, matched, mb, lane);
+                sym = lit_decode_regs(r, lit, sub, !st_is_char(state), match_byte, lane);
             } else
 #endif
             if (!st_is_char(state)) {
-                uint32_t mb = (uint64_t)rep0 < now ? uni(out[now - 1 - rep0]) : 0;
+                uint32_t mb = match_byte;
                 while (sym < 0x100) {
                     uint32_t mbit = (mb >> 7) & 1;
                     mb <<= 1;
@@ -417,13 +429,9 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
             } else {
                 while (sym < 0x100) sym = (sym << 1) | rd_bit(r, lit, sub + sym);
             }
-            if (r.eof) {
-                status = ST_TRUNCATED;
-                break;
-            }
             prev = sym & 0xFF;
-            if (now >= out_cap) {
-                status = ST_OUT_CAP;
+            if (now >= r.lim) {
+                status = r.eof ? ST_TRUNCATED : ST_OUT_CAP;
                 break;
             }
             if (lane == 0) out[now] = (uint8_t)prev;
@@ -487,42 +495,53 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
                 } else
                     rep0 = slot;
             }
-            if (r.eof) {
-                status = ST_TRUNCATED;
+            if (rep0 >= (now < dict_check ? now : dict_check)) {
+                status = r.eof ? ST_TRUNCATED : ST_STREAM;
                 break;
             }
-            if ((uint64_t)rep0 >= now || rep0 >= dict_check) {
-                status = ST_STREAM;
-                break;
-            }
-            if (now + len > out_cap) {
-                status = ST_OUT_CAP;
+            if (now + len > r.lim) {
+                status = r.eof ? ST_TRUNCATED : ST_OUT_CAP;
                 break;
             }
             // lzOutWindow.copyBlock (lz_window.go:48-64) copies byte by byte, so a
             // source that overlaps the destination repeats with period D = rep0 + 1.
             // Byte i of the copy therefore equals out[now - D + (i mod D)], which only
             // reads bytes written before this match: the lanes can copy in parallel.
+            // Element `len` of the same sequence is the byte the match would have continued
+            // with, which a literal that follows is coded against (lzma_decoder.go:248-252);
+            // it is fetched along with the copy.
             {
-                const uint64_t D = (uint64_t)rep0 + 1;
-                const uint8_t *src = out + now - D;
+                const uint32_t D = rep0 + 1;
+                const uint8_t *src = out + (now - D);
+                uint8_t *dst = out + now;
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
                 // make earlier single-lane literal stores visible to every lane
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#endif
-                for (uint32_t i = lane; i < len; i += nlanes) {
-                    uint64_t k = i < D ? i : i % D;
-                    out[now + i] = src[k];
+                uint32_t v = 0;
+                if (len < nlanes && len < D) {  // one pass, nothing repeats
+                    if (lane <= len) {
+                        v = src[lane];
+                        if (lane < len) dst[lane] = (uint8_t)v;
+                    }
+                } else {
+                    for (uint32_t i = lane; i <= len; i += nlanes) {
+                        v = src[i < D ? i : i % D];
+                        if (i < len) dst[i] = (uint8_t)v;
+                    }
                 }
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+                prev = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)((len - 1) & 63u));
+                match_byte = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(len & 63u));
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#else
+                for (uint32_t i = 0; i < len; i++) dst[i] = src[i < D ? i : i % D];
+                prev = dst[len - 1];
+                match_byte = src[len < D ? len : len % D];
 #endif
                 now += len;
-                uint32_t last = len - 1;
-                prev = uni(src[last < D ? last : last % D]);
             }
         }
     }
+    if (status == ST_OK && now == end && (unpack < 0 || unpack > (int64_t)end)) status = ST_OUT_CAP;  // longer than supported
     res.status = status;
     res.out_size = now;
     return res;
