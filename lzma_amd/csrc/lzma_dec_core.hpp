@@ -393,16 +393,23 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
     r.lim = out_cap < kMaxStreamOut ? (uint32_t)out_cap : kMaxStreamOut;
     for (int i = 0; i < 5; i++) r.code = (r.code << 8) | rd_byte(r);
 
-    const uint32_t dict_check = h.dict_size > 1 ? h.dict_size : 1;
+    // distances from 2^31 on are the end marker or an error (lzma_decoder.go:283-288); folded
+    // into the dictionary limit so that one comparison rejects all of them
+    const uint32_t dict_check = h.dict_size > 0x80000000u ? 0x80000000u : h.dict_size > 1 ? h.dict_size : 1;
     const uint32_t ps_mask = (1u << h.pb) - 1, lp_mask = (1u << h.lp) - 1, lc = h.lc;
     const int64_t unpack = h.unpack_size;
-    const uint32_t end = unpack < 0 || unpack > (int64_t)kMaxStreamOut ? kMaxStreamOut : (uint32_t)unpack;
+    const uint32_t last = unpack < 0 || unpack > (int64_t)kMaxStreamOut ? kMaxStreamOut : (uint32_t)unpack;
     uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
     uint32_t now = 0;
     uint32_t prev = 0;
     uint32_t match_byte = 0;  // the byte the last match would have continued with
     int32_t status = ST_OK;
+    bool marker = false;
 
+    // The loop has one exit, its condition: whatever ends the stream early sets `end` to zero.
+    // (With several exits the compiler routes each through a selector variable that is tested
+    // again and again on the way out, on every symbol.)
+    uint32_t end = last;
     while (now < end) {
         uint32_t ps = now & ps_mask;
         if (rd_bit(r, probs, P_IS_MATCH + (state << kPosStatesBitsMax) + ps) == 0) {
@@ -430,13 +437,14 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
                 while (sym < 0x100) sym = (sym << 1) | rd_bit(r, lit, sub + sym);
             }
             prev = sym & 0xFF;
-            if (now >= r.lim) {
+            if (now < r.lim) {
+                if (lane == 0) out[now] = (uint8_t)prev;
+                now++;
+                state = st_char(state);
+            } else {
                 status = r.eof ? ST_TRUNCATED : ST_OUT_CAP;
-                break;
+                end = 0;
             }
-            if (lane == 0) out[now] = (uint8_t)prev;
-            now++;
-            state = st_char(state);
         } else {
             uint32_t len;
             if (rd_bit(r, probs, P_IS_REP + state) == 1) {
@@ -482,35 +490,30 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
                     } else {
                         rep0 += rd_direct(r, nd - kAlignBits) << kAlignBits;
                         rep0 += bt_rev_decode(r, probs, P_ALIGN, kAlignBits);
-                        if ((int32_t)rep0 < 0) {
-                            if (r.eof) {
-                                status = ST_TRUNCATED;
-                                break;
-                            }
-                            if (rep0 == 0xFFFFFFFFu) break;  // end marker
-                            status = ST_STREAM;
-                            break;
-                        }
                     }
                 } else
                     rep0 = slot;
             }
             if (rep0 >= (now < dict_check ? now : dict_check)) {
-                status = r.eof ? ST_TRUNCATED : ST_STREAM;
-                break;
-            }
-            if (now + len > r.lim) {
+                // too far back, or (from 2^31 on) the end marker 0xFFFFFFFF
+                if (r.eof)
+                    status = ST_TRUNCATED;
+                else if (rep0 == 0xFFFFFFFFu)
+                    marker = true;
+                else
+                    status = ST_STREAM;
+                end = 0;
+            } else if (now + len > r.lim) {
                 status = r.eof ? ST_TRUNCATED : ST_OUT_CAP;
-                break;
-            }
-            // lzOutWindow.copyBlock (lz_window.go:48-64) copies byte by byte, so a
-            // source that overlaps the destination repeats with period D = rep0 + 1.
-            // Byte i of the copy therefore equals out[now - D + (i mod D)], which only
-            // reads bytes written before this match: the lanes can copy in parallel.
-            // Element `len` of the same sequence is the byte the match would have continued
-            // with, which a literal that follows is coded against (lzma_decoder.go:248-252);
-            // it is fetched along with the copy.
-            {
+                end = 0;
+            } else {
+                // lzOutWindow.copyBlock (lz_window.go:48-64) copies byte by byte, so a
+                // source that overlaps the destination repeats with period D = rep0 + 1.
+                // Byte i of the copy therefore equals out[now - D + (i mod D)], which only
+                // reads bytes written before this match: the lanes can copy in parallel.
+                // Element `len` of the same sequence is the byte the match would have continued
+                // with, which a literal that follows is coded against (lzma_decoder.go:248-252);
+                // it is fetched along with the copy.
                 const uint32_t D = rep0 + 1;
                 const uint8_t *src = out + (now - D);
                 uint8_t *dst = out + now;
@@ -541,7 +544,7 @@ LZ_HD DecodeResult decode_stream(const uint8_t *in, uint64_t n, const Header &h,
             }
         }
     }
-    if (status == ST_OK && now == end && (unpack < 0 || unpack > (int64_t)end)) status = ST_OUT_CAP;  // longer than supported
+    if (status == ST_OK && !marker && now == last && (unpack < 0 || unpack > (int64_t)last)) status = ST_OUT_CAP;  // longer than supported
     res.status = status;
     res.out_size = now;
     return res;
