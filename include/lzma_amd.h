@@ -126,7 +126,8 @@ void lzma_amd_release_workspace(void);
  * with capacity out_off[s+1]-out_off[s]; out_sizes[s] receives the number of
  * bytes produced and status[s] the per-stream status.  On a non-OK status the
  * bytes produced before the error are left in place (the reference would have
- * delivered only whole flushed windows of them).
+ * delivered only whole flushed windows of them).  One stream may produce at most
+ * 4 GiB - 512 bytes; a longer one ends with LZMA_AMD_ERR_OUT_CAP.
  */
 int lzma_amd_decode_batch(const uint8_t *in, const uint64_t *in_off, size_t n_streams,
                           uint8_t *out, const uint64_t *out_off, uint64_t *out_sizes,

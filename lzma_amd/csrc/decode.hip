@@ -5,15 +5,18 @@
 // applied once per stream.  A stream is a serial chain, and the throughput of the device
 // grows almost linearly with the number of streams a CU holds (measured from 2 to 10 per
 // CU), so the state kept in LDS is cut to the 3.6 KiB of non-literal models and a CU holds
-// 32 streams, as many as it has wave slots.  The literal models (12 KiB at lc 3) live in a per-workgroup HBM area behind the L2
-// and are walked in registers, one fetch per literal (lzma_dec_core.hpp).  The
-// range-decoder state is wave-uniform and is kept in scalar registers; the match copy is
-// done by all 64 lanes.  Each workgroup owns one literal area and loops over the streams
-// blockIdx, blockIdx + gridDim, ...  Streams whose literal coder is larger than the area (lc+lp > 4) are
-// deferred to a second launch with few workgroups and full-size areas.
+// 32 streams, as many as it has wave slots (the kernel stays within 64 vector and 96 scalar
+// registers for that).  The literal models (12 KiB at lc 3) live in a per-workgroup HBM
+// area behind the L2 and are walked in registers, one fetch per literal
+// (lzma_dec_core.hpp).  At 32 waves per CU the kernel is bound by instruction issue, so the
+// bit step is divided between the scalar and the vector unit by hand (lzma_dec_core.hpp);
+// the match copy is done by all 64 lanes.  Each workgroup owns one literal area and loops
+// over the streams blockIdx, blockIdx + gridDim, ...  Streams whose literal coder is larger
+// than the area (lc+lp > 4) are deferred to a second launch with few workgroups and
+// full-size areas.
 //
 // Roofline class: HBM-bound in principle (reads C compressed bytes, writes N raw
-// bytes per stream), serial-dependency-bound in practice.
+// bytes per stream), instruction-issue-bound in practice.
 #include <algorithm>
 
 #include "host_util.hpp"
