@@ -53,6 +53,16 @@ def pmc_traffic(kernel, input_bytes_per_launch):
     return int(k["hbm_bytes_per_input_byte_reported"] * input_bytes_per_launch)
 
 
+def pmc_traffic_decode(output_bytes_per_launch):
+    """The same for decode_kernel, whose summary is per output byte."""
+    path = ROOT / "profiles" / "r01_pmc_decode_125k_streams.json"
+    try:
+        k = json.loads(path.read_text())["decode_kernel_per_output_byte"]
+        return int(k["hbm_bytes_per_output_byte_reported"] * output_bytes_per_launch)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dist_init(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,7 +266,8 @@ class DecodeWorkload:
         gbs = alg / (avg_ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "decode_kernel", "achieved": round(gbs, 4),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 8),
-                "traffic": None, "kernel_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg}
+                "traffic": pmc_traffic_decode(self.n), "kernel_ms": round(avg_ms, 3),
+                "algorithmic_bytes_per_launch": alg}
 
     def cpu_baseline(self, budget_streams=3000):
         from oracle import oracle as O

@@ -77,3 +77,24 @@ def test_errors(amd, data_lzma, data_txt):
     assert status[2] == rc and (rc != 0 or outs[2] == out)
     assert status[3] == N.ERR_OUT_CAP
     assert status[4] == N.OK and outs[4] == data_txt
+
+
+def test_truncated_streams_match_oracle(amd, data_txt):
+    """A stream cut at any byte: the status and the bytes delivered before the input ran out
+    equal the oracle's, whether the cut falls in a literal, in a match or in the end marker,
+    and whether or not the missing byte would only have been needed by the last normalisation."""
+    from oracle import oracle as O
+    raw = data_txt[5000:9000]
+    cuts, streams, want = [], [], []
+    for eos in (False, True):
+        full = O.encode(raw, O.params(dict_log=16, fb=64, lc=3, lp=0, pb=2, eos=eos))
+        points = list(range(13, 40)) + list(range(40, len(full) - 24, 53)) + list(range(len(full) - 24, len(full) + 1))
+        for c in points:
+            s = full[:c]
+            cuts.append((eos, c, len(full)))
+            streams.append(s)
+            want.append(O.decode(s, out_cap=len(raw)))
+    status, outs = amd.decode_batch(streams, out_caps=[len(raw)] * len(streams))
+    for (eos, c, n), st, o, (rc, ref) in zip(cuts, status, outs, want):
+        assert st == rc, (eos, c, n, int(st), rc)
+        assert o == ref, (eos, c, n, len(o), len(ref))
