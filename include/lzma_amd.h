@@ -113,9 +113,10 @@ int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off, si
 /* The encoder keeps its streams and device memory (match-finder tables and match
  * lists, up to about 250 bytes per input byte of the largest batch of chunks seen)
  * with the calling thread from one call to the next, because allocating and
- * releasing that much takes seconds.  This gives it back.  No counterpart in the
- * reference (its encoder state lives and dies with each writer,
- * lzma_encoder.go:1120-1136). */
+ * releasing that much takes seconds; lzma_amd_bt4_matches keeps its tables and
+ * lists (about 120 bytes per input byte) the same way, until the thread's next
+ * encoder call.  This gives both back.  No counterpart in the reference (its
+ * encoder state lives and dies with each writer, lzma_encoder.go:1120-1136). */
 void lzma_amd_release_workspace(void);
 
 /* --------------------------------------------------------------------- decoder

@@ -298,6 +298,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     if ((uint64_t)resident * lit_stride * sizeof(lz::prob_t) > lit_budget)
         resident = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
 
+    lzh::release_finder_workspace();  // what a match-finder call of this thread kept is needed here
     // batches: whole chunks, at most batch_bytes each (a larger chunk is a batch of its own)
     const uint64_t total = off[n_chunks] - off[0];
     uint64_t batch_bytes = 832ull << 20;
@@ -429,6 +430,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
 
 extern "C" void lzma_amd_release_workspace(void) {
     if (g_ws) g_ws->release();
+    lzh::release_finder_workspace();
 }
 
 extern "C" int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off, size_t n_chunks,

@@ -507,6 +507,24 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
 
 }  // namespace lzh
 
+namespace {
+struct FinderWs {
+    int device = -1;
+    lzh::MfScratch scratch;
+    lzh::MfResult res;
+};
+// never destroyed on its own: at process exit the HIP runtime may already be gone
+thread_local FinderWs *g_fws = nullptr;
+}  // namespace
+
+void lzh::release_finder_workspace() {
+    if (!g_fws || g_fws->device < 0) return;
+    (void)hipDeviceSynchronize();
+    g_fws->scratch.release();
+    g_fws->res.release();
+    g_fws->device = -1;
+}
+
 extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_t dict_size,
                                         uint32_t fb, uint32_t *d_counts, uint64_t *d_offsets,
                                         uint32_t *d_pairs, size_t pairs_cap, uint64_t *d_total_pairs,
@@ -528,8 +546,17 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     const uint32_t N = (uint32_t)n;
     lzh::Timer t_all, t_scan;
     t_all.start(st);
-    lzh::MfScratch ws;
-    lzh::MfResult res;
+    // tables and lists (about 120 bytes per input byte) stay with the calling thread, as the
+    // encoder's do: allocating and releasing them costs more than the kernels at these sizes
+    int dev = 0;
+    LZ_HIP(hipGetDevice(&dev));
+    if (!g_fws) g_fws = new FinderWs;
+    if (g_fws->device != dev) {
+        lzh::release_finder_workspace();
+        g_fws->device = dev;
+    }
+    lzh::MfScratch &ws = g_fws->scratch;
+    lzh::MfResult &res = g_fws->res;
     int rc = ws.build(d_data, N, dict_size, fb, st);
     if (rc) return rc;
     lzh::DevBuf joff;

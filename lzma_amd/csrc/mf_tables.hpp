@@ -60,4 +60,7 @@ struct MfResult {
 int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t base, uint64_t j0,
             uint32_t njobs, hipStream_t st, uint64_t *total_pairs);
 
+// Gives back the tables and lists that lzma_amd_bt4_matches keeps with the calling thread.
+void release_finder_workspace();
+
 }  // namespace lzh
