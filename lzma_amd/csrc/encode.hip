@@ -394,7 +394,9 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
         const uint32_t nchunks = (uint32_t)(c1 - c0);
         t_mf[b].start(S.mf);
-        // the sort temporaries live in the arena the scan is about to fill
+        // the sort temporaries live in the arena the scan is about to fill; the first batch's
+        // sorts run before any encode launch of this call
+        scratch.alone = b == 0;
         if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
                                 sl.res.arena.bytes)))
             return bail(rc);

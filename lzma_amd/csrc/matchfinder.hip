@@ -142,20 +142,22 @@ unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 256 * 32) {
     return (unsigned)(g < max_blocks ? g : max_blocks);
 }
 
-// Sort configuration: the merge-sort path of the library's radix sort for every size.
-// Its default for large inputs, the single-pass ("onesweep") radix sort, makes no progress
-// while an encode kernel of another stream is resident (measured: its first pass sits
-// until the first encode workgroup exits, about 5 s, whatever its workgroup size), which
-// would serialize the finder/encoder pipeline; the merge path runs next to it unhindered.
-using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                           rocprim::default_config, ~(size_t)0>;
+// Sort configurations.  The library's default for large inputs, the single-pass ("onesweep")
+// radix sort, is about three times faster than its merge-sort path here, but makes no progress
+// while an encode kernel of another stream is resident (measured: its first pass sits until the
+// first encode workgroup exits, about 5 s, whatever its workgroup size), which would serialize
+// the finder/encoder pipeline; the merge path runs next to it unhindered.  So the default is
+// used when the finder has the device to itself (MfScratch::alone) and the merge path otherwise.
+using MergeCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                            rocprim::default_config, ~(size_t)0>;
+using AloneCfg = rocprim::default_config;
 
-template <class K>
+template <class Cfg, class K>
 size_t sort_temp_bytes(uint32_t n, unsigned end_bit) {
     rocprim::counting_iterator<uint32_t> iota(0);
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, (K *)nullptr, (K *)nullptr, iota, (uint32_t *)nullptr, n,
-                                    0, end_bit, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs<Cfg>(nullptr, bytes, (K *)nullptr, (K *)nullptr, iota, (uint32_t *)nullptr, n,
+                                         0, end_bit, (hipStream_t) nullptr);
     return bytes;
 }
 
@@ -166,29 +168,31 @@ size_t scan_temp_bytes(uint32_t n) {
     return bytes;
 }
 
+template <class Cfg, class K, class V>
+int sort_pairs_cfg(lzh::MfScratch &s, K *keys_in, K *keys_out, V vals_in, uint32_t *vals_out, uint32_t n,
+                   unsigned end_bit, hipStream_t st) {
+    size_t bytes = 0;
+    LZ_HIP(rocprim::radix_sort_pairs<Cfg>(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st));
+    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
+    bytes = s.temp_bytes;
+    LZ_HIP(rocprim::radix_sort_pairs<Cfg>(s.temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st));
+    return LZMA_AMD_OK;
+}
+
+// values out = the positions 0..n-1 ordered by key
 template <class K>
 int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n,
                 unsigned end_bit, hipStream_t st) {
     rocprim::counting_iterator<uint32_t> iota(0);
-    size_t bytes = 0;
-    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
-                                     st));
-    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
-    bytes = s.temp_bytes;
-    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp, bytes, keys_in, keys_out, iota, vals_out, n, 0, end_bit,
-                                     st));
-    return LZMA_AMD_OK;
+    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st)
+                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
 }
 
 // same with the values given (stable: equal keys keep the order of vals_in)
 int sort_values_by_key(lzh::MfScratch &s, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in,
                        uint32_t *vals_out, uint32_t n, hipStream_t st) {
-    size_t bytes = 0;
-    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
-    if (bytes > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
-    bytes = s.temp_bytes;
-    LZ_HIP(rocprim::radix_sort_pairs<SortCfg>(s.temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st));
-    return LZMA_AMD_OK;
+    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, 64, st)
+                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, 64, st);
 }
 
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
@@ -321,18 +325,23 @@ namespace lzh {
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or scan of n items
+template <class Cfg>
+static size_t lib_temp_bytes_cfg(uint32_t n) {
     size_t t = 0;
     const unsigned bits32[] = {10, 16, 23, 32};
-    for (unsigned b : bits32) t = std::max(t, sort_temp_bytes<uint32_t>(n, b));
-    t = std::max(t, sort_temp_bytes<uint64_t>(n, 64));
+    for (unsigned b : bits32) t = std::max(t, sort_temp_bytes<Cfg, uint32_t>(n, b));
+    t = std::max(t, sort_temp_bytes<Cfg, uint64_t>(n, 64));
     {
         size_t b = 0;
-        (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                                 (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64,
-                                                 (hipStream_t) nullptr);
+        (void)rocprim::radix_sort_pairs<Cfg>(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64,
+                                             (hipStream_t) nullptr);
         t = std::max(t, b);
     }
+    return t;
+}
+static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or scan of n items
+    size_t t = std::max(lib_temp_bytes_cfg<MergeCfg>(n), lib_temp_bytes_cfg<AloneCfg>(n));
     t = std::max(t, scan_temp_bytes(n));
     return t + 256;
 }
@@ -557,6 +566,7 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     }
     lzh::MfScratch &ws = g_fws->scratch;
     lzh::MfResult &res = g_fws->res;
+    ws.alone = true;
     int rc = ws.build(d_data, N, dict_size, fb, st);
     if (rc) return rc;
     lzh::DevBuf joff;

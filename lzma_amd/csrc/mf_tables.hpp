@@ -24,6 +24,9 @@ struct MfScratch {
     // temporaries of one build: sort keys in/out, sorted positions, group starts, library scratch
     void *kin = nullptr, *kout = nullptr, *vout = nullptr, *grp = nullptr, *temp = nullptr;
     size_t temp_bytes = 0;
+    // No encode kernel is resident while this build's sorts run: they may use the library's
+    // single-pass radix sort (see matchfinder.hip).  Set by the caller before build().
+    bool alone = false;
     // Makes room for the tables of batches of up to n positions (n < 2^32 - 64).
     int reserve(uint32_t n);
     // Bytes of temporaries a build of n positions needs.
