@@ -145,9 +145,12 @@ unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 256 * 32) {
 // Sort configurations.  The library's default for large inputs, the single-pass ("onesweep")
 // radix sort, is about three times faster than its merge-sort path here, but makes no progress
 // while an encode kernel of another stream is resident (measured: its first pass sits until the
-// first encode workgroup exits, about 5 s, whatever its workgroup size), which would serialize
-// the finder/encoder pipeline; the merge path runs next to it unhindered.  So the default is
-// used when the finder has the device to itself (MfScratch::alone) and the merge path otherwise.
+// first encode workgroup exits, about 5 s), which would serialize the finder/encoder pipeline:
+// its histogram kernel wants 32 KiB of LDS and its sort kernel 108 registers in each of the four
+// waves of a block, and twelve resident encode waves leave a CU 7 KiB and 56 registers per SIMD.
+// (A single-wave configuration that fits, 64 threads x 6 items x 6 bits, runs but is slower than
+// the merge path.)  The merge path runs next to the encoder unhindered.  So the default is used
+// when the finder has the device to itself (MfScratch::alone) and the merge path otherwise.
 using MergeCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                             rocprim::default_config, ~(size_t)0>;
 using AloneCfg = rocprim::default_config;
