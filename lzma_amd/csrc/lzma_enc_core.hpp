@@ -27,8 +27,9 @@
 //                match length -- so applying them per entry gives the same table.)
 //   * the non-literal models, the 16-bit price tables and a ring window of the
 //     optimum table that follows `cur` live in LDS; the full 4096-entry table sits
-//     in HBM (written through), because on text the parse runs to the end of it
-//     almost every time;
+//     in HBM, because on text the parse runs to the end of it almost every time: an
+//     entry is written there once, when the parse position reaches it (entries beyond
+//     the window directly);
 //   * match lengths are measured eight bytes at a time;
 //   * getPosSlot is computed with a count-leading-zeros instead of a 2 KiB table.
 //
@@ -239,24 +240,33 @@ struct Encoder {
         return in_win(i) ? o_rec[i & (kRecWin - 1)].price : opt_g[i].rec.price;
     }
     LZ_HD uint32_t opp(uint32_t i) const { return in_win(i) ? o_rec[i & (kRecWin - 1)].pp : opt_g[i].rec.pp; }
+    // An entry inside the window lives in LDS alone until the parse position reaches it:
+    // only then is it final, and commit_rec() writes it to HBM once (entries ahead of cur
+    // are updated many times; writing each update through cost a memory store per lane and
+    // step, and every later wait for a load waited for those stores too).  Entries beyond
+    // the window are written to HBM directly and fetched when the window reaches them.
     LZ_HD void set_price(uint32_t i, uint32_t v) {
-        opt_g[i].rec.price = v;
-        if (in_win(i)) o_rec[i & (kRecWin - 1)].price = v;
-    }
-    LZ_HD void set_pp(uint32_t i, uint32_t v) {
-        opt_g[i].rec.pp = v;
-        if (in_win(i)) o_rec[i & (kRecWin - 1)].pp = v;
+        if (in_win(i)) o_rec[i & (kRecWin - 1)].price = v; else opt_g[i].rec.price = v;
     }
     // price, backPrev and path word in one go (backPrev2 keeps its old value)
     LZ_HD void set_pbp(uint32_t i, uint32_t price, uint32_t back, uint32_t ppw) {
-        opt_g[i].rec.price = price, opt_g[i].rec.back = back, opt_g[i].rec.pp = ppw;
         if (in_win(i)) {
             LZ_LDS Rec *r = o_rec + (i & (kRecWin - 1));
             r->price = price, r->back = back, r->pp = ppw;
+        } else {
+            opt_g[i].rec.price = price, opt_g[i].rec.back = back, opt_g[i].rec.pp = ppw;
         }
     }
-    LZ_HD void u_set_pp(uint32_t i, uint32_t v) {
-        if (one()) set_pp(i, v);
+    // entry i (inside the window, wave-uniform value r) is final: to HBM, path word to LDS
+    LZ_HD void commit_rec(uint32_t i, const Rec &r) {
+        if (one()) {
+            opt_g[i].rec = r;
+            o_rec[i & (kRecWin - 1)].pp = r.pp;
+        }
+    }
+    // the same for an entry whose LDS copy is complete (the end of a parse)
+    LZ_HD void commit_from_window(uint32_t i) {
+        if (one()) opt_g[i].rec = o_rec[i & (kRecWin - 1)];
     }
     LZ_HD void u_set_pbp(uint32_t i, uint32_t price, uint32_t back, uint32_t ppw) {
         if (one()) set_pbp(i, price, back, ppw);
@@ -265,8 +275,7 @@ struct Encoder {
         if (one()) sbks(i, v);
     }
     LZ_HD void srec(uint32_t i, const Rec &v) {
-        opt_g[i].rec = v;
-        if (in_win(i)) o_rec[i & (kRecWin - 1)] = v;
+        if (in_win(i)) o_rec[i & (kRecWin - 1)] = v; else opt_g[i].rec = v;
     }
     // Uniform helpers: loads are issued first and made uniform afterwards, so that
     // several are in flight at once.
@@ -771,7 +780,11 @@ struct Encoder {
                 back_res = back1;
                 return 1;
             }
-            u_set_pp(0, state << 24);
+            {
+                Rec r0_;
+                r0_.price = 0, r0_.back = 0, r0_.pp = state << 24, r0_.back2 = 0;
+                commit_rec(0, r0_);
+            }
             Reps b0;
             b0.r[0] = r0, b0.r[1] = r1, b0.r[2] = r2, b0.r[3] = r3;
             u_sbks(0, b0);
@@ -792,7 +805,10 @@ struct Encoder {
         uint32_t cur = 0;
         for (;;) {
             cur++;
-            if (cur == len_end) return backward(cur);
+            if (cur == len_end) {
+                commit_from_window(cur);
+                return backward(cur);
+            }
             win_advance(cur);
             LZ_LAP(5)
             uint32_t new_len = read_match_distances();
@@ -801,6 +817,7 @@ struct Encoder {
             if (new_len >= fb) {
                 longest_len = new_len;
                 longest_found = 1;
+                commit_from_window(cur);
                 return backward(cur);
             }
             position++;
@@ -851,7 +868,11 @@ struct Encoder {
                     r0 = pos - kNumReps, r1 = q0, r2 = q1, r3 = q2;
                 }
             }
-            u_set_pp(cur, (cw & ~(0xFu << 24)) | (st << 24));
+            {
+                Rec fr = rc_;
+                fr.pp = (cw & ~(0xFu << 24)) | (st << 24);
+                commit_rec(cur, fr);
+            }
             {
                 Reps nb;
                 nb.r[0] = r0, nb.r[1] = r1, nb.r[2] = r2, nb.r[3] = r3;

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box from the repository root: raw profiling outputs of the encode
+# benchmark into gpurun_out/<tag>/ (condensed afterwards by tools/make_profiles.py).
+#   bash tools/collect_profiles.sh <tag>
+# One rocprofv3 run per counter group; counters never together with a trace.
+set -e -o pipefail
+R=$(pwd)
+OUT=$R/gpurun_out/$1
+mkdir -p "$OUT/pmc"
+cd /tmp
+export TMPDIR=/tmp
+timeout -k 10 300 python3 "$R/bench.py" > "$OUT/bench_default.txt" 2> "$OUT/bench_default.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o enc -- \
+    python3 "$R/bench.py" --no-cpu-baseline --no-verify > "$OUT/ks_enc_log.txt" 2>&1
+cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_raw.csv"
+cp "$(find "$OUT/kt" -name '*kernel_trace.csv' | head -1)" "$OUT/kernel_trace.csv"
+rm -rf "$OUT/kt"
+for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
+         "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
+         "l2:TCC_HIT_sum TCC_MISS_sum"; do
+    n=${g%%:*}
+    c=${g#*:}
+    timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -o p -- \
+        python3 "$R/bench.py" --chunks 832 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmc_$n.log" 2>&1
+    cp "$(find "$OUT/pmc_$n" -name '*counter_collection.csv' | head -1)" "$OUT/pmc/$n.csv"
+    rm -rf "$OUT/pmc_$n"
+    echo "pmc pass $n done"
+done

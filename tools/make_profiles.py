@@ -1,15 +1,18 @@
-"""Turns the raw outputs of one profiling run into the summaries kept under profiles/.
+"""Turns the raw outputs of tools/collect_profiles.sh into the encode summaries kept under profiles/.
 
     python tools/make_profiles.py gpurun_out/<run> r01 832
 
-The run directory holds what the profiling command writes on the GPU box:
-  bench_default.txt / bench_mf.txt / bench_decode.txt   stdout of the three bench.py runs
-  kernel_stats.csv, timeline.txt                        from rocprofv3 --kernel-trace --stats on bench.py
-  pmc/{fetch,write,sq,l2}.csv                           rocprofv3 --pmc passes on bench.py --chunks N --steps 1
+The run directory holds what the collection script writes on the GPU box:
+  bench_default.txt                       stdout of a plain bench.py run
+  ks_enc_log.txt, kernel_stats_raw.csv,
+  kernel_trace.csv                        rocprofv3 --kernel-trace --stats --output-format csv on bench.py
+  pmc/{fetch,write,sq,l2}.csv             rocprofv3 --pmc passes on bench.py --chunks N --steps 1
+(The match-finder and decode summaries come from the same commands with --workload mf / decode.)
 """
 import collections
 import csv
 import json
+import re
 import sys
 from pathlib import Path
 
@@ -28,20 +31,58 @@ def kernel_class(name):
     return "other"
 
 
+def short_name(name):
+    """Kernel names without argument lists; library kernels by their rocprim entry point and key type."""
+    m = re.search(r"(encode_kernel|decode_kernel<\w+>|mf_\w+_kernel(<[^>]*>)?)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"wrapped_(\w+?)_config<[^;,]*[;,] *unsigned (long|int)", name)
+    if m:
+        return f"rocprim::{m.group(1)} <{'u64' if m.group(2) == 'long' else 'u32'} keys>"
+    m = re.search(r"rocprim::\w+::detail::(\w+)", name)
+    if m:
+        return "rocprim::" + m.group(1)
+    return name.split("(")[0][:80]
+
+
+def bench_line(path):
+    lines = [l for l in path.read_text(errors="replace").splitlines() if l.startswith('{"metric"')]
+    return lines[-1]
+
+
 def main():
     run, tag, chunks = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
     prof = ROOT / "profiles"
     prof.mkdir(exist_ok=True)
-    for wl in ("default", "mf", "decode"):
-        lines = [l for l in (run / f"bench_{wl}.txt").read_text(errors="replace").splitlines() if l.startswith('{"metric"')]
-        (prof / f"{tag}_bench_{'encode' if wl == 'default' else wl}.json").write_text(lines[-1] + "\n")
-    (prof / f"{tag}_encode_default_kernel_stats.csv").write_text(
-        "# rocprofv3 --kernel-trace --stats -- python3 bench.py   (defaults: 4096 x 1 MiB chunks, 1 warmup + 2 timed "
-        "steps; MI355X; durations in microseconds; view top_kernels of the rocpd database)\n"
-        + (run / "kernel_stats.csv").read_text())
-    (prof / f"{tag}_encode_default_timeline.txt").write_text(
-        "# kernel timeline of the same run (ms since the first kernel): E = encode_kernel launch (start end duration "
-        "grid), scan = mf_scan_kernel, k = other finder kernels over 30 ms\n" + (run / "timeline.txt").read_text())
+    (prof / f"{tag}_bench_encode.json").write_text(bench_line(run / "bench_default.txt") + "\n")
+    same = json.loads(bench_line(run / "ks_enc_log.txt"))
+    rows = list(csv.DictReader(open(run / "kernel_stats_raw.csv")))
+    keep = [r for r in rows if kernel_class(r["Name"]) != "other"]
+    with open(prof / f"{tag}_encode_default_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-verify  (defaults: 4096 x "
+                "1 MiB chunks, 1 warmup + 2 timed steps; MI355X; durations in ns; library kernel names shortened to "
+                "their rocprim entry point)  -- the bench line of this same run: "
+                f"value {same['value']} MB/s, ms_per_step {same['ms_per_step']:.1f}, roofline.kernel_ms "
+                f"{same['roofline']['kernel_ms']} (= the encode_kernel average below)\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+        for r in keep:
+            f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
+                                                                       "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+    trace = sorted(csv.DictReader(open(run / "kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+    ours = [r for r in trace if kernel_class(r["Kernel_Name"]) != "other"]
+    t0 = int(ours[0]["Start_Timestamp"])
+    with open(prof / f"{tag}_encode_default_timeline.txt", "w") as f:
+        f.write("# kernel timeline of the same run (ms since the first finder kernel): E = encode_kernel launch (start "
+                "end duration grid), scan = mf_scan_kernel, k = other finder kernels over 30 ms\n")
+        for r in ours:
+            b, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+            nm = r["Kernel_Name"]
+            if "encode_kernel" in nm:
+                f.write(f"E   {b:9.1f} {e:9.1f} {e - b:8.1f} grid {int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}\n")
+            elif "mf_scan" in nm:
+                f.write(f"  scan {b:9.1f} {e:9.1f} {e - b:8.1f}\n")
+            elif e - b > 30:
+                f.write(f"    k  {b:9.1f} {e:9.1f} {e - b:8.1f} {short_name(nm)}\n")
     out = {}
     for d in ("fetch", "write", "sq", "l2"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
