@@ -76,26 +76,18 @@ __global__ __launch_bounds__(256) void mf_head_kernel(const K *__restrict__ skey
         head[j] = (j > 0 && skey[j - 1] != skey[j]) ? j : 0;
 }
 
-// 16-gram groups: skey holds bytes 0..7 of the sorted positions, bytes 8..15 come from the text
-__global__ __launch_bounds__(256) void mf_head16_kernel(const uint8_t *__restrict__ data, uint32_t n,
-                                                        const uint64_t *__restrict__ skey,
-                                                        const uint32_t *__restrict__ ord,
-                                                        uint32_t *__restrict__ head) {
+// 16-gram key of position i: the 8-gram group of i and the 8-gram group of i + 8 (a group's
+// start index in the 8-gram table names it), so that one sort orders the positions by their
+// first 16 bytes.  The last 8 positions of the text get keys of their own: no search looks at
+// them (a search at level 16 needs 16 bytes after its position and only meets older ones).
+__global__ __launch_bounds__(256) void mf_key16_kernel(const MfInfo *__restrict__ info, uint32_t n,
+                                                       uint64_t *__restrict__ keys) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        bool same = j > 0 && skey[j - 1] == skey[j];
-        if (same) same = lz::mf_load8(data, n, ord[j - 1] + 8) == lz::mf_load8(data, n, ord[j] + 8);
-        head[j] = same ? 0 : j;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t hi = info[i].g8;
+        const uint32_t lo = i + 8 < n ? info[i + 8].g8 : (0x80000000u | i);
+        keys[i] = ((uint64_t)hi << 32) | lo;
     }
-}
-
-// keys[j] = bytes 0..7 of position ord[j]
-__global__ __launch_bounds__(256) void mf_gather_key_kernel(const uint8_t *__restrict__ data, uint32_t n,
-                                                            const uint32_t *__restrict__ ord,
-                                                            uint64_t *__restrict__ keys) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
-        keys[j] = lz::mf_load8(data, n, ord[j]);
 }
 
 // ent[j] = {ord[j], 8 bytes at data[ord[j] + sig_off]};  rank of ord[j] = j, its group starts at gstart[j]
@@ -189,13 +181,6 @@ int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, 
     rocprim::counting_iterator<uint32_t> iota(0);
     return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st)
                    : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
-}
-
-// same with the values given (stable: equal keys keep the order of vals_in)
-int sort_values_by_key(lzh::MfScratch &s, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in,
-                       uint32_t *vals_out, uint32_t n, hipStream_t st) {
-    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, 64, st)
-                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, 64, st);
 }
 
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
@@ -421,19 +406,14 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
         hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
                            (uint32_t *)grp, 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
     }
-    // 16-gram groups: order by bytes 8..15 first, then (stable) by bytes 0..7
+    // 16-gram groups: one sort by (8-gram group of the position, 8-gram group of the position + 8),
+    // both known from the table just built (fb >= 16 implies the 8-gram table)
     if (view.use16) {
-        hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 8u,
-                           (uint64_t *)kin);
-        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)grp, n, 64, st)))
+        hipLaunchKernelGGL(mf_key16_kernel, dim3(g), dim3(256), 0, st, info.as<MfInfo>(), n, (uint64_t *)kin);
+        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)vout, n, 64, st)))
             return rc;
-        hipLaunchKernelGGL(mf_gather_key_kernel, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)grp,
-                           (uint64_t *)kin);
-        if ((rc = sort_values_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)grp,
-                                     (uint32_t *)vout, n, st)))
-            return rc;
-        hipLaunchKernelGGL(mf_head16_kernel, dim3(g), dim3(256), 0, st, d_data, n, (uint64_t *)kout,
-                           (uint32_t *)vout, (uint32_t *)grp);
+        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (uint64_t *)kout, n,
+                           (uint32_t *)grp);
         if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
         hipLaunchKernelGGL(mf_ent_kernel<16>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
                            (uint32_t *)grp, 16u, ent16.as<MfEnt>(), info.as<MfInfo>());
