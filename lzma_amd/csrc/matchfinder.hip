@@ -2,8 +2,9 @@
 //
 // Replaces lzBinTree.getMatches/skip of the reference (lz_bin_tree.go:115-337) run
 // at every position of a stream.  Pipeline per batch of positions:
-//   1. key kernels: hash-2 / hash-3 / hash-4 slots (lz_bin_tree.go:139-143) and the
-//      first 8 bytes of every position;
+//   1. key kernels: hash-2 / hash-3 / hash-4 slots (lz_bin_tree.go:139-143), the
+//      first 8 bytes of every position, and (from the finished 8-gram table) the pair
+//      of 8-gram groups that stands for its first 16 bytes;
 //   2. stable radix sorts of (key, position) -- rocPRIM device radix sort, the one
 //      library primitive used -- giving each bucket's positions in ascending order;
 //   3. table kernels: 12-byte entries (position, 8 bytes of its text) in sorted order

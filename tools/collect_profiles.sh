@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs on the GPU box from the repository root: raw profiling outputs of the encode
-# benchmark into gpurun_out/<tag>/ (condensed afterwards by tools/make_profiles.py).
+# Runs on the GPU box from the repository root: raw profiling outputs of the encode and
+# match-finder benchmarks into gpurun_out/<tag>/ (condensed afterwards by tools/make_profiles.py).
 #   bash tools/collect_profiles.sh <tag>
 # One rocprofv3 run per counter group; counters never together with a trace.
 set -e -o pipefail
@@ -15,6 +15,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_raw.csv"
 cp "$(find "$OUT/kt" -name '*kernel_trace.csv' | head -1)" "$OUT/kernel_trace.csv"
 rm -rf "$OUT/kt"
+timeout -k 10 300 python3 "$R/bench.py" --workload mf > "$OUT/bench_mf.txt" 2> "$OUT/bench_mf.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktm" -o mf -- \
+    python3 "$R/bench.py" --workload mf --no-cpu-baseline --no-verify > "$OUT/ks_mf_log.txt" 2>&1
+cp "$(find "$OUT/ktm" -name '*kernel_stats.csv' | head -1)" "$OUT/mf_kernel_stats_raw.csv"
+rm -rf "$OUT/ktm"
 for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
          "sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
          "l2:TCC_HIT_sum TCC_MISS_sum"; do

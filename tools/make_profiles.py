@@ -7,7 +7,9 @@ The run directory holds what the collection script writes on the GPU box:
   ks_enc_log.txt, kernel_stats_raw.csv,
   kernel_trace.csv                        rocprofv3 --kernel-trace --stats --output-format csv on bench.py
   pmc/{fetch,write,sq,l2}.csv             rocprofv3 --pmc passes on bench.py --chunks N --steps 1
-(The match-finder and decode summaries come from the same commands with --workload mf / decode.)
+  bench_mf.txt, ks_mf_log.txt,
+  mf_kernel_stats_raw.csv                 the same two runs with --workload mf
+(The decode summaries come from the same commands with --workload decode.)
 """
 import collections
 import csv
@@ -68,6 +70,21 @@ def main():
         for r in keep:
             f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
                                                                        "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+    if (run / "bench_mf.txt").exists():
+        (prof / f"{tag}_bench_mf.json").write_text(bench_line(run / "bench_mf.txt") + "\n")
+        same = json.loads(bench_line(run / "ks_mf_log.txt"))
+        rows = [r for r in csv.DictReader(open(run / "mf_kernel_stats_raw.csv")) if kernel_class(r["Name"]) != "other"]
+        scan = [r for r in rows if "mf_scan" in r["Name"]][0]
+        with open(prof / f"{tag}_mf_kernel_stats.csv", "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload mf --no-cpu-baseline --no-verify  "
+                    "(256 MiB, dict 1 MiB, 1 warmup + 2 timed steps; MI355X; durations in ns; library kernel names "
+                    "shortened to their rocprim entry point)  -- the bench line of this same run: "
+                    f"value {same['value']} MB/s, roofline.kernel_ms {same['roofline']['kernel_ms']} "
+                    f"(mf_scan_kernel average below: {float(scan['AverageNs']) / 1e6:.3f} ms)\n")
+            f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+            for r in rows:
+                f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
+                                                                           "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
     trace = sorted(csv.DictReader(open(run / "kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
     ours = [r for r in trace if kernel_class(r["Kernel_Name"]) != "other"]
     t0 = int(ours[0]["Start_Timestamp"])
