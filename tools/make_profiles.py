@@ -1,4 +1,4 @@
-"""Turns the raw outputs of tools/collect_profiles.sh into the encode summaries kept under profiles/.
+"""Turns the raw outputs of tools/collect_profiles.sh into the encode and match-finder summaries kept under profiles/.
 
     python tools/make_profiles.py gpurun_out/<run> r01 832
 
