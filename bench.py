@@ -402,10 +402,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer", "data": "synthetic",
             "config": wl.config(), "roofline": wl.roofline(),
         }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = wl.cpu_baseline()
-        else:
-            line["cpu_baseline"] = None
+        # the CPU leg is a single-GPU report: with more ranks the others would sit in the final barrier
+        line["cpu_baseline"] = wl.cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
