@@ -19,6 +19,33 @@ def shard_range(n_items: int, rank: int, world: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def shard_by_bytes(sizes, rank: int, world: int):
+    """Contiguous [begin, end) of the items owned by `rank`, balanced by bytes instead of by
+    count: item i goes to the rank whose share of the total holds the item's first byte
+    (rank r's share is bytes [r * total / world, (r + 1) * total / world)).  Every rank
+    computes the same cut from the same `sizes`; ranges are contiguous and cover everything.
+    Used for the decode batch, whose stream sizes differ by a factor of 16."""
+    import numpy as np
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} of {world}")
+    sizes = np.asarray(sizes, dtype=np.int64)
+    n = int(sizes.size)
+    if n == 0:
+        return 0, 0
+    starts = np.cumsum(sizes) - sizes  # first byte of every item
+    total = int(starts[-1] + sizes[-1])
+    if total == 0:
+        return shard_range(n, rank, world)
+    # ceil(r * total / world) in exact integer arithmetic
+    lo = (rank * total + world - 1) // world
+    hi = ((rank + 1) * total + world - 1) // world
+    begin = int(np.searchsorted(starts, lo, side="left"))
+    end = n if rank == world - 1 else int(np.searchsorted(starts, hi, side="left"))
+    if rank == 0:
+        begin = 0
+    return begin, max(begin, end)
+
+
 def shard_counts(n_items: int, world: int):
     return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
 

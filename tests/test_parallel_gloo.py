@@ -90,3 +90,96 @@ def test_offsets_single_rank():
     s = torch.tensor([3, 0, 5], dtype=torch.int64)
     assert parallel.gather_sizes(s, 3, 0, 1).tolist() == [3, 0, 5]
     assert parallel.container_offsets(s).tolist() == [0, 3, 3, 8]
+
+
+def test_shard_by_bytes_balances_and_covers():
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 7, 5000):
+        sizes = rng.integers(4096, 65537, n)
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_by_bytes(sizes, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            if n == 5000:  # no shard is further than one stream from its fair share of the bytes
+                share = sizes.sum() / world
+                for b, e in spans:
+                    assert abs(int(sizes[b:e].sum()) - share) <= 65536
+    # count-balanced sharding of the same sizes would be off by far more than one stream
+    sizes = np.concatenate([np.full(100, 65536), np.full(100, 4096)])
+    b, e = parallel.shard_by_bytes(sizes, 0, 2)
+    assert e < 100 and abs(int(sizes[b:e].sum()) - int(sizes.sum()) // 2) <= 65536
+    assert parallel.shard_by_bytes([0, 0, 0], 1, 2) == parallel.shard_range(3, 1, 2)
+    with pytest.raises(ValueError):
+        parallel.shard_by_bytes([1, 2], 2, 2)
+
+
+def _bytes_worker(rank, world, port, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chunks = _chunks(9)
+        sizes = [len(c) for c in chunks]
+        b, e = parallel.shard_by_bytes(sizes, rank, world)
+        p = O.params(3, eos=True)
+        mine = [O.encode(c, p) for c in chunks[b:e]]
+        # ragged shards of unknown width on the other ranks: gather counts first
+        cnt = torch.tensor([e - b], dtype=torch.int64)
+        allcnt = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allcnt, cnt)
+        counts = [int(c) for c in allcnt]
+        width = max(counts)
+        padded = torch.zeros(width, dtype=torch.int64)
+        padded[: e - b] = torch.tensor([len(s) for s in mine], dtype=torch.int64)
+        out = torch.empty(world * width, dtype=torch.int64)
+        dist.all_gather_into_tensor(out, padded)
+        allsz = torch.cat([out[r * width: r * width + counts[r]] for r in range(world)])
+        off = parallel.container_offsets(allsz)
+        if rank == 0:
+            with open(path, "wb") as f:
+                f.truncate(int(off[-1]))
+        dist.barrier()
+        with open(path, "r+b") as f:
+            for i, s in enumerate(mine):
+                f.seek(int(off[b + i]))
+                f.write(s)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_container_sharded_by_bytes():
+    O.lib()
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "container.bin")
+        mp.spawn(_bytes_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+        got = open(path, "rb").read()
+    p = O.params(3, eos=True)
+    assert got == b"".join(O.encode(c, p) for c in _chunks(9))
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher environment starts two ranks itself (here over
+    gloo with the stub workload: no GPU, no codec) and rank 0 reports n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "stub",
+                        "--backend", "gloo", "--steps", "3", "--warmup", "1", "--chunks", "11"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["chunks_total"] == 11 and line["cpu_baseline"] is None
+    # the same through the launcher the driver uses
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "stub", "--backend", "gloo",
+                        "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
