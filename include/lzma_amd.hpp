@@ -90,36 +90,68 @@ struct Decoded {
     int status;  // LZMA_AMD_OK, _ERR_HEADER, _ERR_STREAM, _ERR_TRUNCATED, ...
 };
 
+// What a stream of n compressed bytes can expand to at most: the cheapest symbol is a
+// 273-byte rep0 match coded in 14 binary decisions, none cheaper than log2(2048/2017) bits,
+// i.e. fewer than 7100 output bytes per compressed byte; one stream produces at most
+// 4 GiB - 512 bytes (lzma_amd.h).  Capacities taken from an untrusted header are clamped to
+// this, so a forged size field cannot make a batch allocate terabytes.
+inline uint64_t MaxOutput(uint64_t n) {
+    const uint64_t lim = ((uint64_t)1 << 32) - 512, v = 64 + 7200 * n;
+    return v < lim ? v : lim;
+}
+
 // Complete .lzma streams (13-byte header + payload).  Output capacity comes from the
-// header's size field; for streams that end with a marker instead, from `eos_cap`
-// (bytes per stream), or 40x the compressed size if that is 0.
+// header's size field (clamped to MaxOutput); for streams that end with a marker instead,
+// from `eos_cap` (bytes per stream), or 40x the compressed size if that is 0 -- and every
+// such stream that reports LZMA_AMD_ERR_OUT_CAP is submitted again with eight times the
+// room until it fits or reaches MaxOutput.
 inline std::vector<Decoded> DecodeStreams(const std::vector<std::string> &streams, uint64_t eos_cap = 0) {
     const size_t n = streams.size();
     std::vector<Decoded> res(n);
     if (n == 0) return res;
-    std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0), sizes(n, 0);
-    std::vector<int32_t> status(n, 0);
+    std::vector<uint64_t> cap(n);
+    std::vector<char> grow(n, 0);
+    std::vector<size_t> todo(n);
     for (size_t i = 0; i < n; i++) {
-        in_off[i + 1] = in_off[i] + streams[i].size();
-        uint64_t cap = eos_cap ? eos_cap : 64 + 40 * (uint64_t)streams[i].size();
+        todo[i] = i;
+        const uint64_t lim = MaxOutput(streams[i].size());
         uint32_t lc, lp, pb, dict;
         int64_t unpack = -1;
         if (lzma_amd_parse_header((const uint8_t *)streams[i].data(), streams[i].size(), &lc, &lp, &pb, &dict,
-                                  &unpack) == LZMA_AMD_OK &&
-            unpack >= 0 && unpack < ((int64_t)1 << 40))
-            cap = (uint64_t)unpack;
-        out_off[i + 1] = out_off[i] + cap;
+                                  &unpack) == LZMA_AMD_OK && unpack >= 0) {
+            cap[i] = (uint64_t)unpack < lim ? (uint64_t)unpack : lim;
+        } else {
+            cap[i] = eos_cap ? eos_cap : 64 + 40 * (uint64_t)streams[i].size();
+            if (cap[i] > lim) cap[i] = lim;
+            grow[i] = 1;
+        }
     }
-    std::string in;
-    in.reserve(in_off[n]);
-    for (const auto &s : streams) in += s;
-    std::string out(out_off[n] ? out_off[n] : 1, '\0');
-    const int rc = lzma_amd_decode_batch((const uint8_t *)in.data(), in_off.data(), n, (uint8_t *)&out[0],
-                                         out_off.data(), sizes.data(), status.data());
-    if (rc != LZMA_AMD_OK) throw DeviceError(rc);
-    for (size_t i = 0; i < n; i++) {
-        res[i].status = status[i];
-        res[i].data = out.substr(out_off[i], sizes[i]);
+    while (!todo.empty()) {
+        const size_t m = todo.size();
+        std::vector<uint64_t> in_off(m + 1, 0), out_off(m + 1, 0), sizes(m, 0);
+        std::vector<int32_t> status(m, 0);
+        std::string in;
+        for (size_t k = 0; k < m; k++) {
+            in_off[k + 1] = in_off[k] + streams[todo[k]].size();
+            out_off[k + 1] = out_off[k] + cap[todo[k]];
+            in += streams[todo[k]];
+        }
+        std::string out(out_off[m] ? out_off[m] : 1, '\0');
+        const int rc = lzma_amd_decode_batch((const uint8_t *)in.data(), in_off.data(), m, (uint8_t *)&out[0],
+                                             out_off.data(), sizes.data(), status.data());
+        if (rc != LZMA_AMD_OK) throw DeviceError(rc);
+        std::vector<size_t> again;
+        for (size_t k = 0; k < m; k++) {
+            const size_t i = todo[k];
+            res[i].status = status[k];
+            res[i].data = out.substr(out_off[k], sizes[k]);
+            const uint64_t lim = MaxOutput(streams[i].size());
+            if (status[k] == LZMA_AMD_ERR_OUT_CAP && grow[i] && cap[i] < lim) {
+                cap[i] = 8 * cap[i] < lim ? 8 * cap[i] : lim;
+                again.push_back(i);
+            }
+        }
+        todo.swap(again);
     }
     return res;
 }

@@ -31,29 +31,36 @@ def _ptr(a):
     return a.ctypes.data if a.size else None
 
 
+# An LZMA stream cannot expand without bound: the cheapest symbol is a 273-byte rep0 match
+# coded in 14 binary decisions, none cheaper than log2(2048/2017) bits (a model saturates at
+# 2017/2048), i.e. fewer than 7100 output bytes per compressed byte.  Capacities derived
+# from an untrusted header are clamped to this, so a forged size field cannot make a batch
+# allocate terabytes.
+MAX_EXPANSION = 7200
+MAX_STREAM_OUT = (1 << 32) - 512  # what one stream may produce (include/lzma_amd.h)
+
+
+def max_output(stream_len: int) -> int:
+    return min(MAX_STREAM_OUT, 64 + MAX_EXPANSION * int(stream_len))
+
+
 def header_sizes(streams):
-    """Output capacity needed per stream: header size field when present."""
+    """Size field of each stream's header: None for -1 (end marker) or a short stream."""
     caps = []
     for s in streams:
         cap = None
         if len(s) >= 13:
             sz = int.from_bytes(s[5:13], "little", signed=True)
-            if 0 <= sz < (1 << 40):
+            if sz >= 0:
                 cap = sz
         caps.append(cap)
     return caps
 
 
-def decode_batch(streams, out_caps=None):
-    """Decode complete .lzma streams.  Returns (statuses[int32], [bytes])."""
+def _decode_once(streams, caps):
     n = len(streams)
-    if n == 0:
-        return np.zeros(0, np.int32), []
-    if out_caps is None:
-        out_caps = [c if c is not None else 64 + 40 * len(s)
-                    for c, s in zip(header_sizes(streams), streams)]
     in_off = _offsets([len(s) for s in streams])
-    out_off = _offsets(out_caps)
+    out_off = _offsets(caps)
     src = np.frombuffer(b"".join(bytes(s) for s in streams), dtype=np.uint8)
     out = np.empty(max(int(out_off[-1]), 1), dtype=np.uint8)
     sizes = np.zeros(n, dtype=np.uint64)
@@ -62,6 +69,51 @@ def decode_batch(streams, out_caps=None):
                                           out_off.ctypes.data, sizes.ctypes.data,
                                           status.ctypes.data))
     res = [out[int(out_off[i]): int(out_off[i]) + int(sizes[i])].tobytes() for i in range(n)]
+    return status, res
+
+
+def decode_batch(streams, out_caps=None, max_batch_bytes=8 << 30):
+    """Decode complete .lzma streams.  Returns (statuses[int32], [bytes]).
+
+    Output capacity per stream: the header's size field when it has one (clamped to what
+    the compressed length can possibly expand to); for streams that end with a marker
+    instead, 40x the compressed size at first, and every stream that reports ERR_OUT_CAP is
+    submitted again with eight times the room until it fits or reaches that clamp.  Batches
+    whose capacities add up to more than max_batch_bytes are decoded in several calls.
+    Explicit out_caps are used as given, without retry."""
+    n = len(streams)
+    if n == 0:
+        return np.zeros(0, np.int32), []
+    status = np.zeros(n, dtype=np.int32)
+    res = [b""] * n
+    if out_caps is not None:
+        caps = [int(c) for c in out_caps]
+        grow = [False] * n
+    else:
+        hs = header_sizes(streams)
+        caps = [min(h, max_output(len(s))) if h is not None else min(64 + 40 * len(s), max_output(len(s)))
+                for h, s in zip(hs, streams)]
+        grow = [h is None for h in hs]
+    todo = list(range(n))
+    while todo:
+        # groups of streams whose capacities fit the per-call budget
+        groups, cur, tot = [], [], 0
+        for i in todo:
+            if cur and tot + caps[i] > max_batch_bytes:
+                groups.append(cur)
+                cur, tot = [], 0
+            cur.append(i)
+            tot += caps[i]
+        groups.append(cur)
+        again = []
+        for g in groups:
+            st, out = _decode_once([streams[i] for i in g], [caps[i] for i in g])
+            for k, i in enumerate(g):
+                status[i], res[i] = st[k], out[k]
+                if st[k] == N.ERR_OUT_CAP and grow[i] and caps[i] < max_output(len(streams[i])):
+                    caps[i] = min(8 * caps[i], max_output(len(streams[i])))
+                    again.append(i)
+        todo = again
     return status, res
 
 

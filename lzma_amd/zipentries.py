@@ -56,7 +56,8 @@ def read_lzma_entries(zf: zipfile.ZipFile, names=None, check_crc: bool = True):
         fp.seek(info.header_offset + 30 + name_len + extra_len)
         raw = fp.read(info.compress_size)
         streams.append(entry_stream(raw, info.file_size, bool(info.flag_bits & 2)))
-        caps.append(info.file_size)
+        # the directory's size is untrusted too: never more room than the entry can expand to
+        caps.append(min(info.file_size, codec.max_output(len(raw) + 4)))
     status, outs = codec.decode_batch(streams, out_caps=caps)
     res = {}
     for info, st, data in zip(infos, status, outs):

@@ -98,3 +98,39 @@ def test_truncated_streams_match_oracle(amd, data_txt):
     for (eos, c, n), st, o, (rc, ref) in zip(cuts, status, outs, want):
         assert st == rc, (eos, c, n, int(st), rc)
         assert o == ref, (eos, c, n, len(o), len(ref))
+
+
+def test_highly_compressible_eos_stream_is_retried(amd):
+    """A stream that ends with a marker carries no size: the first guess of its output
+    capacity (40x the compressed bytes) is far too small for 1 MiB of zeros (about 1 KiB
+    compressed), and the batch call must come back with more room instead of failing --
+    NewWriter (size -1) to NewReader round trip, as TestBoth does with text."""
+    import io
+    from oracle import oracle as O
+    payloads = [bytes(1 << 20), b"ab" * 300000, b"x"]
+    for payload in payloads:
+        buf = io.BytesIO()
+        w = amd.NewWriterLevel(buf, 3)
+        w.write(payload)
+        w.close()
+        assert len(buf.getvalue()) * 40 + 64 < len(payload) or len(payload) < 100
+        assert amd.NewReader(io.BytesIO(buf.getvalue())).read() == payload
+    streams = [O.encode(p, O.params(3, eos=True)) for p in payloads]
+    status, outs = amd.decode_batch(streams)
+    assert (status == 0).all() and outs == payloads
+
+
+def test_forged_size_field_does_not_size_the_batch(amd, data_txt):
+    """A header that claims 2^39 bytes must not make the call allocate them: the capacity is
+    clamped to what the compressed bytes can expand to, the other streams of the batch
+    decode normally and the forged one ends with a per-stream status."""
+    from lzma_amd import _native as N
+    from lzma_amd import codec
+    from oracle import oracle as O
+    good = O.encode(data_txt[:20000], O.params(3, eos=False))
+    forged = bytearray(good)
+    forged[5:13] = (1 << 39).to_bytes(8, "little")
+    assert codec.max_output(len(forged)) < (1 << 28)
+    status, outs = amd.decode_batch([good, bytes(forged), good])
+    assert status[0] == 0 and status[2] == 0 and outs[0] == outs[2] == data_txt[:20000]
+    assert status[1] != 0 and outs[1][:20000] == data_txt[:20000]
