@@ -99,7 +99,8 @@ int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_t dict_size
  * capacity given to chunk c (use lzma_amd_encode_bound).  status[c] is per
  * chunk.  Every chunk is an independent stream, as if passed to its own
  * NewWriterSizeLevel.  The header's size field is the chunk length unless
- * p->eos.
+ * p->eos.  In the device form in_total is the number of bytes addressable from
+ * d_in; offsets beyond it are rejected with LZMA_AMD_ERR_ARG.
  */
 int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off, size_t n_chunks,
                            const lzma_amd_params *p, uint8_t *out, const uint64_t *out_off,
@@ -111,12 +112,17 @@ int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off, si
                                int32_t *d_status, void *stream);
 
 /* The encoder keeps its streams and device memory (match-finder tables and match
- * lists, up to about 250 bytes per input byte of the largest batch of chunks seen)
- * with the calling thread from one call to the next, because allocating and
- * releasing that much takes seconds; lzma_amd_bt4_matches keeps its tables and
- * lists (about 120 bytes per input byte) the same way, until the thread's next
- * encoder call.  This gives both back.  No counterpart in the reference (its
- * encoder state lives and dies with each writer, lzma_encoder.go:1120-1136). */
+ * lists, up to about 230 bytes per input byte of the largest batch of chunks seen;
+ * batches are at most 1 GiB) with the calling thread from one call to the next,
+ * because allocating and releasing that much takes seconds; lzma_amd_bt4_matches
+ * keeps its tables and lists (about 120 bytes per input byte) the same way, until
+ * the thread's next encoder call.  Every entry point may be called from any thread,
+ * but what the threads keep adds up: the environment variable
+ * LZMA_AMD_WORKSPACE_GIB bounds what one encoder thread may hold (its batches
+ * shrink to fit), for processes that run several encoder threads, or an encoder
+ * next to decode calls, on one device.  This call gives back what the calling
+ * thread keeps.  No counterpart in the reference (its encoder state lives and dies
+ * with each writer, lzma_encoder.go:1120-1136). */
 void lzma_amd_release_workspace(void);
 
 /* --------------------------------------------------------------------- decoder

@@ -33,6 +33,7 @@ namespace {
 // for consecutive positions almost all the time, so the words of the next position's
 // list (one per lane) and the result word of the position after it are requested
 // one call ahead and are usually there when needed.
+template <bool PACKED>
 struct MfFunctor {
     static __device__ uint64_t uni64(uint64_t v) {
         return ((uint64_t)lz::U((uint32_t)(v >> 32)) << 32) | lz::U((uint32_t)v);
@@ -43,15 +44,27 @@ struct MfFunctor {
     uint32_t pf_pos;
     uint64_t pf_meta, pf_meta2;
     uint32_t pf_word;
+    // words of a list of c pairs, and the list's first word in the arena
+    static __device__ uint32_t words(uint32_t c) { return PACKED ? c : 2 * c; }
+    static __device__ uint64_t first(uint64_t m) { return PACKED ? lz::mf_meta_off(m) : 2 * lz::mf_meta_off(m); }
+    // word k of a list goes to the (length, distance) array the parse reads
+    static __device__ void put(LZ_LDS uint32_t *out, uint32_t k, uint32_t w) {
+        if (PACKED) {
+            out[2 * k] = lz::mf_pack_len(w);
+            out[2 * k + 1] = lz::mf_pack_dist(w);
+        } else {
+            out[k] = w;
+        }
+    }
     __device__ uint32_t operator()(uint32_t pos, LZ_LDS uint32_t *out) {
         const bool hit = pos == pf_pos;
         const uint64_t m = uni64(hit ? pf_meta : meta[job_start + pos]);
         const uint32_t c = lz::mf_meta_count(m);
-        if (hit && 2 * c <= 64) {
-            if (lane < 2 * c) out[lane] = pf_word;
+        if (hit && words(c) <= 64) {
+            if (lane < words(c)) put(out, lane, pf_word);
         } else {
-            const uint32_t *src = arena + 2 * lz::mf_meta_off(m);
-            for (uint32_t k = lane; k < 2 * c; k += 64) out[k] = src[k];
+            const uint32_t *src = arena + first(m);
+            for (uint32_t k = lane; k < words(c); k += 64) put(out, k, src[k]);
         }
         uint32_t g1 = job_start + pos + 1, g2 = job_start + pos + 2;
         if (g1 >= n_total) g1 = n_total - 1;
@@ -59,7 +72,7 @@ struct MfFunctor {
         const uint64_t m1 = uni64(hit ? pf_meta2 : meta[g1]);
         const uint32_t c1 = lz::mf_meta_count(m1);
         uint32_t w = 0;
-        if (2 * c1 <= 64 && lane < 2 * c1) w = arena[2 * lz::mf_meta_off(m1) + lane];
+        if (words(c1) <= 64 && lane < words(c1)) w = arena[first(m1) + lane];
         pf_word = w;
         pf_meta = m1;
         pf_meta2 = meta[g2];
@@ -85,6 +98,7 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb) {
 
 // Chunks [c0, c0 + nchunks) of the call; their bytes start at data offset
 // in_off[c] - base inside t.data.
+template <bool PACKED>
 __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
                                                     const uint64_t *__restrict__ mf_meta,
                                                     const uint32_t *__restrict__ mf_arena,
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         for (uint32_t i = lane; i < lit_n; i += 64) lit[i] = lz::kProbInit;
         __syncthreads();
 
-        lz::Encoder<MfFunctor, lz::prob_t *> e;
+        lz::Encoder<MfFunctor<PACKED>, lz::prob_t *> e;
         e.data = data + jb;
         e.n = je - jb;
         e.readable = data_n - jb;
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         e.lane_id = lane;
         e.out = out + ob + lz::kHeaderSize;
         e.out_cap = oe - ob - lz::kHeaderSize;
-        e.mf = MfFunctor{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
+        e.mf = MfFunctor<PACKED>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
         e.ep = ep;
 #if defined(LZ_PROFILE)
         for (int i = 0; i < 12; i++) e.prof[i] = 0;
@@ -147,8 +161,9 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         e.run(small);
 #if defined(LZ_PROFILE)
         if (lane == 0 && blockIdx.x == 0)
-            printf("PROF chunk n=%u: mf %llu | stateA %llu | round %llu | mid %llu | apply %llu | loopctl %llu | getopt_other %llu | emit %llu\n",
-                   e.n, (unsigned long long)e.prof[0], (unsigned long long)e.prof[1], (unsigned long long)e.prof[2],
+            printf("PROF chunk n=%u: mf %llu | path %llu | prices %llu | round %llu | lit %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | getopt_other %llu | emit %llu\n",
+                   e.n, (unsigned long long)e.prof[0], (unsigned long long)e.prof[8], (unsigned long long)e.prof[1],
+                   (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[10],
                    (unsigned long long)e.prof[3], (unsigned long long)e.prof[4], (unsigned long long)e.prof[5],
                    (unsigned long long)e.prof[6], (unsigned long long)e.prof[7]);
 #endif
@@ -178,10 +193,22 @@ int check_params(const lzma_amd_params *p) {  // checkValues, lzma_encoder.go:11
 
 constexpr uint64_t kMaxChunkBytes = 1ull << 30;  // largest single chunk
 constexpr uint64_t kMinBatchBytes = 128ull << 20; // a batch is not cut below this for its chunk count
-constexpr unsigned kNumCU = 256;
-constexpr unsigned kLdsPerCU = 160u << 10;
-constexpr unsigned kMaxChainsPerCU = 12;          // three waves per SIMD at the kernel's register count
+constexpr unsigned kWavesPerSimd = 3;             // what the kernel's register count (136..168) allows
 constexpr int kEncStreams = 3;                    // encode launches in flight
+
+// What the launch arithmetic needs to know about the device, read once per device.
+struct DeviceShape {
+    unsigned cus = 0, lds_per_cu = 0, simds_per_cu = 4;
+};
+int device_shape(int dev, DeviceShape &d) {
+    hipDeviceProp_t pr;
+    LZ_HIP(hipGetDeviceProperties(&pr, dev));
+    d.cus = (unsigned)pr.multiProcessorCount;
+    d.lds_per_cu = (unsigned)pr.maxSharedMemoryPerMultiProcessor;
+    if (d.lds_per_cu == 0) d.lds_per_cu = (unsigned)pr.sharedMemPerBlock;
+    if (d.cus == 0 || d.lds_per_cu == 0) return lzh::fail(LZMA_AMD_ERR_HIP, "device reports no compute units or no LDS");
+    return LZMA_AMD_OK;
+}
 
 // Everything one batch in flight owns.
 struct Slot {
@@ -196,24 +223,29 @@ struct Slot {
 // would share a queue and run one after the other).
 //
 // Streams and device memory are kept by the calling thread from one call to the next
-// (about 250 bytes per input byte of the largest batch seen, up to some 230 GB for 1 MiB
-// chunks): allocating and releasing that much costs seconds per call.
-// lzma_amd_release_workspace() gives it back.
+// (about 230 bytes per input byte of the largest batch seen, with one-word match pairs):
+// allocating and releasing that much costs seconds per call.  The environment variable
+// LZMA_AMD_WORKSPACE_GIB bounds what one thread may hold (batches shrink to fit), so that
+// several encoder threads, or an encoder and a decoder, can share a device;
+// lzma_amd_release_workspace() gives everything back.
 struct Workspace {
     int device = -1;
+    DeviceShape shape;
     hipStream_t mf = nullptr, enc[kEncStreams] = {};  // enc[0] is the caller's, set per call
     hipEvent_t in_ready = nullptr;
     lzh::MfScratch scratch;
     Slot slots[kEncStreams + 1];
     uint64_t bytes() const {
-        uint64_t b = scratch.ent4.bytes + scratch.ent8.bytes + scratch.ent16.bytes + scratch.info.bytes +
-                     scratch.own_tmp.bytes;
+        uint64_t b = scratch.bytes();
         for (const auto &sl : slots) b += sl.res.meta.bytes + sl.res.arena.bytes + sl.opt.bytes + sl.lit.bytes;
         return b;
     }
     int prepare(int dev) {
         if (device == dev) return LZMA_AMD_OK;
         release();
+        device = dev;  // from here on release() undoes whatever was created
+        int rc = device_shape(dev, shape);
+        if (rc) return rc;
         LZ_HIP(hipStreamCreateWithFlags(&mf, hipStreamNonBlocking));
         for (int i = 1; i < kEncStreams; i++) LZ_HIP(hipStreamCreateWithFlags(&enc[i], hipStreamNonBlocking));
         LZ_HIP(hipEventCreateWithFlags(&in_ready, hipEventDisableTiming));
@@ -221,7 +253,6 @@ struct Workspace {
             LZ_HIP(hipEventCreate(&sl.e0));
             LZ_HIP(hipEventCreate(&sl.e1));
         }
-        device = dev;
         return LZMA_AMD_OK;
     }
     void release() {
@@ -248,17 +279,28 @@ struct Workspace {
 // never destroyed on its own: at process exit the HIP runtime may already be gone
 thread_local Workspace *g_ws = nullptr;
 
+template <bool PACKED>
+int launch_encode(unsigned grid, unsigned lds, hipStream_t es, const uint8_t *data, uint32_t nbytes,
+                  const lzh::MfResult &res, const uint64_t *d_in_off, uint64_t base, uint64_t c0, uint32_t nchunks,
+                  const lz::EncParams &ep, uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                  int32_t *d_status, lz::OptG *opt, lz::prob_t *lit, uint64_t lit_stride) {
+    hipLaunchKernelGGL(encode_kernel<PACKED>, dim3(grid), dim3(64), lds, es, data, nbytes, res.d_meta(),
+                       res.d_arena(), d_in_off, base, c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
+                       opt, lit, lit_stride);
+    LZ_HIP(hipGetLastError());
+    return LZMA_AMD_OK;
+}
+
 }  // namespace
 
 // The call is cut into batches of whole chunks.  The finder works through the batches on
 // one stream; each batch's encode launch goes to one of kEncStreams other streams as soon
-// as its match lists are complete, so that up to kEncStreams launches (together about
-// kChainsPerCU chunks per CU) run while the finder prepares the next batch.
+// as its match lists are complete, so that up to kEncStreams launches (together as many
+// chunks as the device holds at once) run while the finder prepares the next batch.
 extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off,
                                           size_t n_chunks, size_t in_total, const lzma_amd_params *p,
                                           uint8_t *d_out, const uint64_t *d_out_off,
                                           uint64_t *d_out_sizes, int32_t *d_status, void *stream) {
-    (void)in_total;
     hipStream_t st = (hipStream_t)stream;
     lzh::ThreadState &ts = lzh::tls();
     ts.ms_total = ts.ms_finder = ts.ms_coder = 0.f;
@@ -277,46 +319,69 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
             return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: chunk %zu larger than %llu bytes", c,
                              (unsigned long long)kMaxChunkBytes);
     }
+    // in_total is the size of the caller's input buffer: every chunk must lie inside it
+    if (off[n_chunks] > (uint64_t)in_total)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: chunk offsets reach %llu, beyond the %zu input bytes",
+                         (unsigned long long)off[n_chunks], in_total);
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
     const LdsLayout L = lds_layout(p->pb, p->fb);
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
+    const bool packed = lz::mf_can_pack(ep.dict_size);
+
+    int dev = 0;
+    LZ_HIP(hipGetDevice(&dev));
+    if (!g_ws) g_ws = new Workspace;
+    Workspace &S = *g_ws;
+    if ((rc = S.prepare(dev))) {
+        S.release();
+        return rc;
+    }
 
     // resident workgroups on the whole device: as many per CU as LDS and registers allow
     // (LDS is handed out in 1280-byte units; measured), fewer if the literal models are large.
     // A grid larger than what is really resident would leave workgroups waiting for a whole
     // chunk's time, so the estimate is the minimum of the runtime's and our own.
     const unsigned lds_per_wg = (L.total + 1279u) / 1280u * 1280u;
-    unsigned per_cu = std::min(kMaxChainsPerCU, kLdsPerCU / lds_per_wg);
+    unsigned per_cu = std::min(kWavesPerSimd * S.shape.simds_per_cu, S.shape.lds_per_cu / lds_per_wg);
     {
         int api = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel, 64, L.total) == hipSuccess && api > 0)
-            per_cu = std::min(per_cu, (unsigned)api);
+        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true>, 64, L.total)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false>, 64, L.total);
+        if (e == hipSuccess && api > 0) per_cu = std::min(per_cu, (unsigned)api);
     }
-    unsigned resident = kNumCU * std::max(1u, per_cu);
+    unsigned resident = S.shape.cus * std::max(1u, per_cu);
     const uint64_t lit_budget = 2ull << 30;
     if ((uint64_t)resident * lit_stride * sizeof(lz::prob_t) > lit_budget)
         resident = (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t)));
 
     lzh::release_finder_workspace();  // what a match-finder call of this thread kept is needed here
-    // batches: whole chunks, at most batch_bytes each (a larger chunk is a batch of its own)
-    const uint64_t total = off[n_chunks] - off[0];
-    uint64_t batch_bytes = 832ull << 20;
     int enc_streams = kEncStreams;
-    if (const char *e = getenv("LZMA_AMD_BATCH_MIB")) batch_bytes = (uint64_t)atoi(e) << 20;
     if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
-    {   // a batch costs about 68 B per position of finder tables plus 48 B per position and 1.1 GB
-        // for each of the four match-list slots: shrink it to what the device has free (the
-        // thread's kept workspace counts as free, it is reused)
+    // with many chunks a batch holds the resident workgroups' share of one launch, so that
+    // the launches in flight fill the device exactly; few or small chunks are batched by size
+    // alone (a launch loops over them)
+    const size_t batch_chunks = n_chunks > resident ? std::max(1u, resident / enc_streams) : resident;
+    // Batch size in bytes: the chunk count above at the average chunk size, within what the
+    // device (and the caller's budget) has room for: a batch costs the finder's tables and
+    // sort temporaries once, and meta words and pairs for each match-list slot in flight.
+    const uint64_t total = off[n_chunks] - off[0];
+    const uint64_t avg_chunk = std::max<uint64_t>(1, total / n_chunks);
+    uint64_t batch_bytes = std::max<uint64_t>(kMinBatchBytes, std::min<uint64_t>((uint64_t)batch_chunks * avg_chunk, 1ull << 30));
+    if (const char *e = getenv("LZMA_AMD_BATCH_MIB")) batch_bytes = (uint64_t)atoi(e) << 20;
+    {
         size_t free_b = 0, total_b = 0;
         LZ_HIP(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t avail = (uint64_t)free_b + (g_ws ? g_ws->bytes() : 0);
-        auto need = [](uint64_t b) { return 68 * b + 4 * (48 * b + 1100000000ull) + (1ull << 30); };
-        while (batch_bytes > (64ull << 20) && need(batch_bytes) > avail - avail / 16) batch_bytes -= 64ull << 20;
+        uint64_t avail = (uint64_t)free_b + S.bytes();  // the kept workspace counts as free: it is reused
+        avail -= avail / 16;
+        if (const char *e = getenv("LZMA_AMD_WORKSPACE_GIB")) avail = std::min<uint64_t>(avail, (uint64_t)atoll(e) << 30);
+        const uint64_t per_pos_finder = lzh::MfScratch::bytes_per_position(ep.fb) + 40;  // tables + sort temporaries
+        const uint64_t per_pos_slot = 8 + (packed ? 4 : 8) * 5;
+        auto need = [&](uint64_t b) {
+            return per_pos_finder * b + (uint64_t)(enc_streams + 1) * (per_pos_slot * b + 600000000ull) + (1ull << 30);
+        };
+        while (batch_bytes > (64ull << 20) && need(batch_bytes) > avail) batch_bytes -= 64ull << 20;
     }
-    // with large chunks a batch holds a third of the resident workgroups, so that three
-    // launches fill the device; small chunks are batched by size alone (a launch loops over them)
-    const size_t batch_chunks = n_chunks > resident ? std::max(1u, resident / enc_streams) : resident;
     std::vector<size_t> cut{0};
     for (size_t c = 0; c < n_chunks;) {
         size_t c1 = c + 1;
@@ -333,7 +398,6 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         max_bytes = std::max<uint64_t>(max_bytes, off[cut[b + 1]] - off[cut[b]]);
         max_chunks = std::max(max_chunks, cut[b + 1] - cut[b]);
     }
-    (void)total;
     const unsigned in_flight = (unsigned)std::min<size_t>(nbatches, enc_streams);
     // Workgroups per launch: one per chunk up to this many.  For chunks of even size a launch has
     // about resident / in_flight of them anyway; for many uneven ones, workgroups waiting in the
@@ -344,11 +408,6 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         grid_cap = std::max(1u, (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t))));
     const unsigned max_grid = (unsigned)std::min<size_t>(max_chunks, grid_cap);
 
-    int dev = 0;
-    LZ_HIP(hipGetDevice(&dev));
-    if (!g_ws) g_ws = new Workspace;
-    Workspace &S = *g_ws;
-    if ((rc = S.prepare(dev))) return rc;
     S.enc[0] = st;
     // whatever the caller enqueued on its stream (the inputs) comes first
     LZ_HIP(hipEventRecord(S.in_ready, st));
@@ -363,16 +422,34 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     for (int i = 0; i < nslots; i++) {
         Slot &sl = slots[i];
         sl.busy = false;
-        if ((rc = sl.res.reserve((uint32_t)max_bytes))) return rc;
+        if ((rc = sl.res.reserve((uint32_t)max_bytes, packed ? 4u : 8u))) return rc;
         const size_t opt_bytes = (size_t)max_grid * lz::kNumOpts * sizeof(lz::OptG);
         const size_t lit_bytes = (size_t)max_grid * lit_stride * sizeof(lz::prob_t);
         if (sl.opt.bytes < opt_bytes) LZ_HIP(sl.opt.alloc(opt_bytes));
         if (sl.lit.bytes < lit_bytes) LZ_HIP(sl.lit.alloc(lit_bytes));
     }
+    // the sort temporaries go into the arena the scan is about to fill when that is large enough,
+    // else into memory of their own
+    if (slots[0].res.arena.bytes < lzh::MfScratch::tmp_bytes((uint32_t)max_bytes))
+        if ((rc = scratch.reserve_tmp((uint32_t)max_bytes))) return rc;
     lzh::Timer t_all;
     t_all.start(S.mf);
     std::vector<lzh::Timer> t_mf(nbatches);
     float ms_coder = 0.f;
+    // an error while launches are in flight: let them finish before the caller gets its buffers
+    // back (they write into the caller's outputs and into workspace slots)
+    auto bail = [&](int code) -> int {
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < nslots; i++) slots[i].busy = false;
+        return code;
+    };
+#define LZ_HIP_BAIL(expr)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return bail(lzh::fail(LZMA_AMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                                  hipGetErrorString(e_), __FILE__, __LINE__));                      \
+    } while (0)
     auto retire = [&](Slot &sl) -> int {
         if (!sl.busy) return LZMA_AMD_OK;
         LZ_HIP(hipEventSynchronize(sl.e1));
@@ -380,11 +457,6 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         if (hipEventElapsedTime(&t, sl.e0, sl.e1) == hipSuccess) ms_coder += t;
         sl.busy = false;
         return LZMA_AMD_OK;
-    };
-    // an error while launches are in flight: let them finish before the caller gets its buffers back
-    auto bail = [&](int code) -> int {
-        (void)hipDeviceSynchronize();
-        return code;
     };
     for (size_t b = 0; b < nbatches; b++) {
         Slot &sl = slots[b % nslots];
@@ -394,8 +466,8 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
         const uint32_t nchunks = (uint32_t)(c1 - c0);
         t_mf[b].start(S.mf);
-        // the sort temporaries live in the arena the scan is about to fill; the first batch's
-        // sorts run before any encode launch of this call
+        // the sort temporaries live in the arena the scan is about to fill when it is large
+        // enough; the first batch's sorts run before any encode launch of this call
         scratch.alone = b == 0;
         if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
                                 sl.res.arena.bytes)))
@@ -407,21 +479,24 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         // the finder stream is idle here (mf_scan synchronized it): the lists are complete
         hipStream_t es = S.enc[b % in_flight];
         const unsigned grid = std::min(nchunks, grid_cap);
-        LZ_HIP(hipEventRecord(sl.e0, es));
-        hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), L.total, es, d_in + base, nbytes,
-                           sl.res.d_meta(), sl.res.d_arena(), d_in_off, base, (uint64_t)c0, nchunks, ep, d_out,
-                           d_out_off, d_out_sizes, d_status, sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(),
-                           lit_stride);
-        LZ_HIP(hipGetLastError());
-        LZ_HIP(hipEventRecord(sl.e1, es));
+        LZ_HIP_BAIL(hipEventRecord(sl.e0, es));
+        rc = packed ? launch_encode<true>(grid, L.total, es, d_in + base, nbytes, sl.res, d_in_off, base, (uint64_t)c0,
+                                          nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
+                                          sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride)
+                    : launch_encode<false>(grid, L.total, es, d_in + base, nbytes, sl.res, d_in_off, base, (uint64_t)c0,
+                                           nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
+                                           sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride);
+        if (rc) return bail(rc);
+        LZ_HIP_BAIL(hipEventRecord(sl.e1, es));
         sl.busy = true;
         ts.coder_launches++;
     }
     for (int i = 0; i < nslots; i++)
-        if ((rc = retire(slots[i]))) return rc;
+        if ((rc = retire(slots[i]))) return bail(rc);
     t_all.stop();
-    LZ_HIP(hipStreamSynchronize(S.mf));
-    for (int i = 0; i < (int)in_flight; i++) LZ_HIP(hipStreamSynchronize(S.enc[i]));
+    LZ_HIP_BAIL(hipStreamSynchronize(S.mf));
+    for (int i = 0; i < (int)in_flight; i++) LZ_HIP_BAIL(hipStreamSynchronize(S.enc[i]));
+#undef LZ_HIP_BAIL
     float ms_finder = 0.f;
     for (auto &t : t_mf) ms_finder += t.ms();
     ts.ms_finder = ms_finder;
@@ -459,7 +534,7 @@ extern "C" int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off,
     LZ_HIP(hipMemcpy(d_io.p, in_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
     LZ_HIP(hipMemcpy(d_oo.p, out_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
     rc = lzma_amd_encode_chunks_dev(d_in.as<uint8_t>() - in_base, d_io.as<uint64_t>(), n_chunks,
-                                    in_total, p, d_out.as<uint8_t>() - out_base, d_oo.as<uint64_t>(),
+                                    in_base + in_total, p, d_out.as<uint8_t>() - out_base, d_oo.as<uint64_t>(),
                                     d_sz.as<uint64_t>(), d_st.as<int32_t>(), nullptr);
     if (rc) return rc;
     if (out_total) LZ_HIP(hipMemcpy(out + out_base, d_out.p, out_total, hipMemcpyDeviceToHost));

@@ -835,6 +835,7 @@ struct Encoder {
             const Reps eb_v = gbks(E);
             const uint32_t e_pp = U(e_pp_v);
             const Reps eb = ureps(eb_v);
+            LZ_LAP(8)
             uint32_t st = (e_pp >> 24) & 0xF;
             if (c_p1) {
                 pos_prev--;
@@ -1065,6 +1066,7 @@ struct Encoder {
             }
             if (nx_changed) u_set_pbp(cur + 1, nx_price, nx_back, nx_pp);
             if (!do_rest) continue;
+            LZ_LAP(9)
 
             // ---- continuation of the literal (:635-658)
             for (uint32_t i = 0; i < 5; i++) A.lt[i] = 0, A.lp[i] = 0;
@@ -1090,6 +1092,7 @@ struct Encoder {
                 for (uint32_t ri = 0; ri < kNumReps; ri++)
                     A.rl[ri] = U(v_rl[ri]), A.lt[1 + ri] = U(v_lt[ri]), A.lp[1 + ri] = U(v_lp[ri]);
             }
+            LZ_LAP(10)
             const uint32_t start_len = A.rl[0] >= 2 ? A.rl[0] + 1 : 2;
             for (uint32_t ri = 0; ri < kNumReps; ri++) {
                 const uint32_t lt = A.rl[ri];

@@ -16,46 +16,60 @@
 // prefix maximum over the lanes), then 64 at a time for the positions that need more.
 //
 // To avoid scanning whole buckets (about 1400 candidates per position on text),
-// positions are also grouped by their exact first 8 and first 16 bytes.  All candidates
-// sharing at least 8 bytes with P are in P's 8-gram group; every bucket member newer
-// than the newest of them (Q8) shares fewer than 8.  So the bucket is scanned only down
-// to Q8; from Q8 on the (much shorter) 8-gram group is scanned instead, and that one
-// only down to the newest position sharing 16 bytes (Q16), from where the 16-gram
-// group takes over.
+// positions are also grouped by their exact first 6, 8 and 16 bytes (levels 1..3; the
+// hash-4 bucket is level 0).  All candidates sharing at least k bytes with P are in P's
+// k-gram group; every member of a coarser group that is newer than the newest of them
+// (Qk) shares fewer than k.  So each level is scanned only down to the newest member of
+// the next level's group, from where the (much shorter) finer group takes over.
 //
-// All three scans stream: the sorted tables carry, next to each position, the bytes
-// needed to compare it (bytes 0..7 in the bucket table, 8..15 in the 8-gram table,
-// 16..23 in the 16-gram table), so the lanes read consecutive 12-byte entries instead
-// of gathering from the window; only common prefixes of 24 bytes or more touch the
-// window itself.
+// All scans stream: the sorted tables carry, next to each position, the 8 bytes that
+// follow the bytes its group shares (bytes 0..7 in the bucket table, 6..13, 8..15 and
+// 16..23 in the others), so the lanes read consecutive 12-byte entries instead of
+// gathering from the window; only common prefixes of 24 bytes or more touch the window
+// itself.  A group's oldest entry carries a flag, so a scan knows where its group ends
+// without a second table.
 #pragma once
 #include "lzma_common.hpp"
 
 namespace lz {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMfLevels = 4;
+// bytes the members of a level's group are known to share
+LZ_HD uint32_t mf_known(uint32_t level) { return level == 0 ? 0u : (level == 1 ? 6u : (level == 2 ? 8u : 16u)); }
+constexpr uint32_t kMfFirst = 0x80000000u;  // entry: oldest of its group; rank word: the position is
 
-// One entry of a sorted table: a position and 8 bytes of its text (see above).
+// One entry of a sorted table: a position (bit 31: it is the oldest of its group) and the 8
+// bytes of its text that follow the bytes the group shares.
 struct MfEnt {
     uint32_t pos, sig_lo, sig_hi;
 };
-// Per position: its index in the three tables with the index of the first entry of
-// its bucket / group in each, and the previous position with the same hash-2 / hash-3
-// slot if it starts with the same byte (kNone otherwise).
+// Per position: its index in each level's table (bit 31: it is the oldest of its group there)
+// and the previous position with the same hash-2 / hash-3 slot if it starts with the same byte
+// (kNone otherwise).
 struct __attribute__((aligned(16))) MfInfo {
-    uint32_t rank4, g4, rank8, g8;
-    uint32_t rank16, g16, prev2, prev3;
+    uint32_t rank[kMfLevels];
+    uint32_t prev2, prev3, pad0, pad1;
 };
 
 struct MfTables {
     const uint8_t *data;  // all jobs' bytes, positions are offsets into it
     uint32_t n;           // bytes in data
-    const MfEnt *ent4;    // (hash-4 slot, position) order, sig = bytes 0..7
-    const MfEnt *ent8;    // (bytes 0..7, position) order, sig = bytes 8..15
-    const MfEnt *ent16;   // (bytes 0..15, position) order, sig = bytes 16..23
+    const MfEnt *ent[kMfLevels];  // level l: (group, position) order, sig = bytes known(l) .. known(l)+7
     const MfInfo *info;
-    uint32_t dict, fb, use8, use16;
+    uint32_t dict, fb;
+    uint32_t levels;      // levels built (1 + those whose known bytes do not exceed fb)
+    uint32_t packed;      // pairs are written as one word each (mf_pack) instead of two
 };
+
+// A pair in one word, for dictionaries of up to 8 MiB: length - 2 (at most 271) in bits
+// 0..8, distance - 1 in bits 9..31.  Halves the match lists, which is what limits how many
+// chunks an encode call keeps in flight.
+constexpr uint32_t kMfPackDistBits = 23;
+LZ_HD bool mf_can_pack(uint32_t dict_size) { return dict_size <= (1u << kMfPackDistBits); }
+LZ_HD uint32_t mf_pack(uint32_t len, uint32_t dist) { return (len - 2u) | (dist << 9); }
+LZ_HD uint32_t mf_pack_len(uint32_t w) { return (w & 0x1FFu) + 2u; }
+LZ_HD uint32_t mf_pack_dist(uint32_t w) { return w >> 9; }
 
 // Result word per position: pair offset in the arena (upper 48 bits) and count.
 LZ_HD uint64_t mf_meta(uint64_t off, uint32_t count) { return (off << 16) | count; }
@@ -115,39 +129,81 @@ LZ_D uint32_t row_max_below(uint32_t v) {
     return row_shr<1>(v, 0);
 }
 
-// Output of one row: pairs go to dst[2k], dst[2k+1].
+// Output of one row: pair k goes to dst[2k], dst[2k+1], or packed to dst[k].
 struct MfRowOut {
     uint32_t *dst;
     bool on;  // false: count only (arena full)
+    bool packed;
 };
+LZ_D void mf_put(uint32_t *dst, bool packed, uint32_t k, uint32_t len, uint32_t dist) {
+    if (packed) {
+        dst[k] = mf_pack(len, dist);
+    } else {
+        dst[2 * k] = len;
+        dst[2 * k + 1] = dist;
+    }
+}
 
 LZ_D uint32_t lane_get(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 LZ_D uint64_t lane_get64(uint64_t v, int src) {
     return ((uint64_t)lane_get((uint32_t)(v >> 32), src) << 32) | lane_get((uint32_t)v, src);
 }
 
+// What a row knows about its position before any table entry is looked at: the record of
+// the position and 24 bytes of its text.
+struct MfPos {
+    MfInfo inf;
+    uint64_t p0, p8, p16;  // bytes 0..7, 8..15, 16..23 at P (zero beyond the buffer)
+};
+// The 16 newest entries of every level's group (lane k of the row: the entry k + 1 places
+// below the position's own), requested in one batch.
+struct MfFront {
+    MfEnt e[kMfLevels];
+};
+
+LZ_D void mf_load_pos(const MfTables &t, uint32_t P, bool act, MfPos &a) {
+    a.inf = MfInfo{};
+    a.p0 = a.p8 = a.p16 = 0;
+    if (act) {
+        a.inf = t.info[P];
+        a.p0 = mf_load8(t.data, t.n, P), a.p8 = mf_load8(t.data, t.n, P + 8);
+        a.p16 = mf_load8(t.data, t.n, P + 16);
+    }
+}
+LZ_D void mf_load_front(const MfTables &t, const MfPos &a, bool act, uint32_t idx, MfFront &f) {
+#pragma unroll
+    for (uint32_t l = 0; l < kMfLevels; l++) {
+        f.e[l].pos = 0, f.e[l].sig_lo = 0, f.e[l].sig_hi = 0;
+        const uint32_t r = a.inf.rank[l];
+        // the rank words of levels that were not built are never looked at
+        if (act && l < t.levels && !(r & kMfFirst) && idx < r) f.e[l] = t.ent[l][r - 1 - idx];
+    }
+}
+
 // One level of the scan for every row that has `go` set: entries tab[top-1], tab[top-2],
-// ... down to tab[bottom], newest first, as long as their position is >= low.  `first`
-// holds the 16 newest (lane k of the row: entry top-1-k), fetched by the caller.
-// Candidate lengths are `known` + the bytes sig shares with psig, continued in the window
-// beyond known+8 if `deep`.  A candidate is reported if it is longer than everything newer.
-// Sets fin where a match of len_limit ended the whole search.
+// ... newest first, down to the oldest of the position's group and as long as their
+// position is >= low.  `first` holds the 16 newest (lane k of the row: entry top-1-k),
+// fetched by the caller.  Candidate lengths are `known` + the bytes sig shares with psig,
+// continued in the window beyond known+8 if `deep`.  A candidate is reported if it is
+// longer than everything newer.  Sets fin where a match of len_limit ended the whole search.
 //
 // Most scans end within the first 16 candidates: that step runs for the four rows at once,
 // every lane writing its own pair.  A row that has to go on does so with all 64 lanes of
 // the wave, one such row after the other.
-LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t bottom, const MfEnt &first,
-                   uint32_t low, uint64_t psig, uint32_t known, bool deep, uint32_t P, uint32_t len_limit,
-                   uint32_t &n, uint32_t &max_len, bool &fin, bool go, const MfRowOut &out, uint32_t lane) {
+LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, const MfEnt &first, uint32_t low,
+                   uint64_t psig, uint32_t known, bool deep, uint32_t P, uint32_t len_limit, uint32_t &n,
+                   uint32_t &max_len, bool &fin, bool go, const MfRowOut &out, uint32_t lane) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
-    const uint32_t count = top - bottom;  // entries older than P in the group
-    go = go && !fin && count != 0;
+    go = go && !fin && top != 0;
     if (!__any(go)) return;
     {   // ---- first step, four rows at once
-        bool valid = go && idx < count;
+        const bool inb = go && idx < top;
+        // an entry that is the oldest of its group ends the group: older ones are not candidates
+        const uint32_t ends = row_ballot(inb && (first.pos & kMfFirst) != 0, row_base);
+        bool valid = inb && (ends & ((1u << idx) - 1u)) == 0;
         uint32_t Q = 0, l = 0;
         if (valid) {
-            Q = first.pos;
+            Q = first.pos & ~kMfFirst;
             valid = Q >= low;
             const uint64_t x = (((uint64_t)first.sig_hi << 32) | first.sig_lo) ^ psig;
             l = known + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8);
@@ -161,8 +217,7 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
         const uint32_t m = row_ballot(hit, row_base), vm = row_ballot(valid, row_base);
         if (hit && out.on) {
             const uint32_t k = n + (uint32_t)__builtin_popcount(m & ((1u << idx) - 1u));
-            out.dst[2 * k] = l;
-            out.dst[2 * k + 1] = P - Q - 1;
+            mf_put(out.dst, out.packed, k, l, P - Q - 1);
         }
         // the row's longest candidate so far, from its highest lane
         const uint32_t top_l = (uint32_t)__shfl((int)max(lv, before), (int)(row_base + 15));
@@ -171,27 +226,32 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
             if (top_l > max_len) max_len = top_l;
             if (max_len == len_limit && m != 0) fin = true;  // lz_bin_tree.go:231-235
         }
-        // go on only if every entry of this step was a candidate
-        go = go && !fin && vm == 0xFFFFu && count > 16;
+        // go on only if every entry of this step was a candidate and the group goes on
+        go = go && !fin && vm == 0xFFFFu && ends == 0 && top > 16;
     }
     // ---- rows that go on, one after the other, 64 candidates per step
     unsigned long long pending = __ballot(go && idx == 0);
     while (pending != 0) {
         const int src = __builtin_ctzll(pending);  // first lane of the row
         pending &= pending - 1;
-        const uint32_t u_top = lane_get(top, src), u_count = lane_get(count, src), u_low = lane_get(low, src);
+        const uint32_t u_top = lane_get(top, src), u_low = lane_get(low, src);
         const uint32_t u_P = lane_get(P, src), u_limit = lane_get(len_limit, src);
         const uint64_t u_sig = lane_get64(psig, src);
         uint32_t *u_dst = (uint32_t *)lane_get64((uint64_t)out.dst, src);
         const bool u_on = lane_get((uint32_t)out.on, src) != 0;
+        const bool u_packed = out.packed;  // the same for every row
         uint32_t u_n = lane_get(n, src), u_max = lane_get(max_len, src);
         bool u_fin = false;
-        for (uint32_t done = 16; done < u_count && !u_fin; done += 64) {
-            bool valid = done + lane < u_count;
+        for (uint32_t done = 16; done < u_top && !u_fin; done += 64) {
+            const bool inb = done + lane < u_top;
+            MfEnt e;
+            e.pos = 0, e.sig_lo = 0, e.sig_hi = 0;
+            if (inb) e = tab[u_top - 1 - done - lane];
+            const unsigned long long ends = __ballot(inb && (e.pos & kMfFirst) != 0);
+            bool valid = inb && (ends & ((1ull << lane) - 1ull)) == 0;
             uint32_t Q = 0, l = 0;
             if (valid) {
-                const MfEnt e = tab[u_top - 1 - done - lane];
-                Q = e.pos;
+                Q = e.pos & ~kMfFirst;
                 valid = Q >= u_low;
                 const uint64_t x = (((uint64_t)e.sig_hi << 32) | e.sig_lo) ^ u_sig;
                 l = known + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8);
@@ -204,7 +264,7 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
                 if (m == 0) break;
                 const int f = __builtin_ctzll(m);
                 const uint32_t bl = lane_get(l, f), bq = lane_get(Q, f);
-                if (lane == 0 && u_on) u_dst[2 * u_n] = bl, u_dst[2 * u_n + 1] = u_P - bq - 1;
+                if (lane == 0 && u_on) mf_put(u_dst, u_packed, u_n, bl, u_P - bq - 1);
                 u_n++;
                 u_max = bl;
                 if (bl == u_limit) {
@@ -212,25 +272,19 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t b
                     break;
                 }
             }
-            if (__ballot(valid) != ~0ull) break;
+            if (__ballot(valid) != ~0ull || ends != 0) break;
         }
         if (row_base == (uint32_t)src) n = u_n, max_len = u_max, fin = fin || u_fin;
     }
 }
 
-// Match lists of four positions, one per row.  P, inf (= t.info[P]), the text bytes p0 /
-// p8 / p16 (bytes 0..7, 8..15, 16..23 at P, zero beyond the buffer) and the job
-// [job_start, job_end) are per row;
-// rows with act == false take no part.  Returns the row's number of pairs; the pairs
-// themselves are written through `out` (a later pair with a smaller index overwrites: the
-// reference drops seed pairs that way).
-//
-// Everything that can be addressed from inf -- the 16 newest entries of the bucket, of
-// the 8-gram group and of the 16-gram group -- is requested in one
-// batch, so a typical position costs one memory round trip.
-LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_t p0, uint64_t p8,
-                       uint64_t p16, uint32_t job_start, uint32_t job_end, bool act, const MfRowOut &out,
-                       uint32_t lane) {
+// Match lists of four positions, one per row.  P, `a` (the position's record and text), `f`
+// (the newest entries of its groups) and the job [job_start, job_end) are per row; rows with
+// act == false take no part.  Returns the row's number of pairs; the pairs themselves are
+// written through `out` (a later pair with a smaller index overwrites: the reference drops
+// seed pairs that way).
+LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFront &f, uint32_t job_start,
+                       uint32_t job_end, bool act, const MfRowOut &out, uint32_t lane) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
     const uint32_t left = act ? job_end - P : 0;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
@@ -238,37 +292,38 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_
     // candidate Q is inside the window iff P - Q <= dict (cyclicBufSize = dict+1, :128-131)
     uint32_t W = P > t.dict ? P - t.dict : 0;
     if (W < job_start) W = job_start;
-    const bool use8 = act && t.use8 && len_limit >= 8;
-    const bool use16 = use8 && t.use16 && len_limit >= 16;
 
-    // ---- one batch of loads
-    const uint32_t r4 = inf.rank4, g4 = inf.g4, r8 = inf.rank8, g8 = inf.g8, r16 = inf.rank16, g16 = inf.g16;
-    const uint32_t q2 = inf.prev2, q3 = inf.prev3;
-    MfEnt a0, b0, c0;
-    a0.pos = 0, a0.sig_lo = 0, a0.sig_hi = 0;
-    b0 = a0, c0 = a0;
-    if (act && idx < r4 - g4) a0 = t.ent4[r4 - 1 - idx];
-    if (use8 && idx < r8 - g8) b0 = t.ent8[r8 - 1 - idx];
-    if (use16 && idx < r16 - g16) c0 = t.ent16[r16 - 1 - idx];
     // inf.prev2 / prev3 are kNone unless that position starts with P's first byte
+    const uint32_t q2 = a.inf.prev2, q3 = a.inf.prev3;
     const bool hit2 = act && q2 != kNone && q2 >= W, hit3 = act && q3 != kNone && q3 >= W;
 
-    const uint32_t a_new = row_first(a0.pos, row_base), b_new = row_first(b0.pos, row_base),
-                   c_new = row_first(c0.pos, row_base);
+    // per level: the position's rank, whether it has an older member of its group at all, and
+    // the newest such member
+    uint32_t top[kMfLevels], newest[kMfLevels];
+    bool has[kMfLevels];
+#pragma unroll
+    for (uint32_t l = 0; l < kMfLevels; l++) {
+        const uint32_t r = a.inf.rank[l];
+        // a level is used if it was built and the position has that many bytes to compare
+        const bool use = act && l < t.levels && (l == 0 || len_limit >= mf_known(l));
+        has[l] = use && !(r & kMfFirst) && r != 0;
+        top[l] = has[l] ? r : 0u;
+        newest[l] = row_first(f.e[l].pos, row_base) & ~kMfFirst;
+    }
     uint32_t q4 = kNone;
-    if (act && r4 > g4 && a_new >= job_start) q4 = a_new;
+    if (has[0] && newest[0] >= job_start) q4 = newest[0];
     uint32_t n = 0, max_len = 1, last = q2;
     const bool lead = idx == 0 && out.on;
     // seeds, lz_bin_tree.go:154-180
     if (hit2) {
         max_len = 2;
-        if (lead) out.dst[0] = 2u, out.dst[1] = P - q2 - 1;
+        if (lead) mf_put(out.dst, out.packed, 0, 2u, P - q2 - 1);
         n = 1;
     }
     if (hit3) {
         if (q3 == q2) n--;
         max_len = 3;
-        if (lead) out.dst[2 * n] = 3u, out.dst[2 * n + 1] = P - q3 - 1;
+        if (lead) mf_put(out.dst, out.packed, n, 3u, P - q3 - 1);
         n++;
         last = q3;
     }
@@ -277,17 +332,22 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfInfo &inf, uint64_
         max_len = 1;
     }
 
-    // newest positions sharing P's first 8 and first 16 bytes
-    uint32_t q8s = kNone, q16s = kNone;
-    if (use8 && r8 > g8 && b_new >= W) q8s = b_new;
-    if (use16 && r16 > g16 && c_new >= W) q16s = c_new;
-    // the hash-4 bucket down to Q8, the 8-gram group down to Q16, the 16-gram group
+    // each level down to the newest in-window member of the next level's group
     bool fin = false;
-    mf_level(t, t.ent4, r4, g4, a0, q8s != kNone ? q8s + 1 : W, p0, 0, false, P, len_limit, n, max_len, fin, act,
-             out, lane);
-    mf_level(t, t.ent8, r8, g8, b0, q16s != kNone ? q16s + 1 : W, p8, 8, false, P, len_limit, n, max_len, fin,
-             q8s != kNone, out, lane);
-    mf_level(t, t.ent16, r16, g16, c0, W, p16, 16, true, P, len_limit, n, max_len, fin, q16s != kNone, out, lane);
+    bool go[kMfLevels];
+#pragma unroll
+    for (uint32_t l = 0; l < kMfLevels; l++) go[l] = has[l] && (l == 0 || newest[l] >= W);
+#pragma unroll
+    for (uint32_t l = 0; l < kMfLevels; l++) {
+        const uint32_t low = (l + 1 < kMfLevels && go[l + 1]) ? newest[l + 1] + 1 : W;
+        uint64_t psig;
+        if (l == 0) psig = a.p0;
+        else if (l == 1) psig = (a.p0 >> 48) | (a.p8 << 16);
+        else if (l == 2) psig = a.p8;
+        else psig = a.p16;
+        mf_level(t, t.ent[l], top[l], f.e[l], low, psig, mf_known(l), l + 1 == kMfLevels, P, len_limit, n, max_len,
+                 fin, go[l], out, lane);
+    }
     return n;
 }
 

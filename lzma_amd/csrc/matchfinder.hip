@@ -2,20 +2,24 @@
 //
 // Replaces lzBinTree.getMatches/skip of the reference (lz_bin_tree.go:115-337) run
 // at every position of a stream.  Pipeline per batch of positions:
-//   1. key kernels: hash-2 / hash-3 / hash-4 slots (lz_bin_tree.go:139-143), the
-//      first 8 bytes of every position, and (from the finished 8-gram table) the pair
-//      of 8-gram groups that stands for its first 16 bytes;
+//   1. key kernels: hash-2 / hash-3 / hash-4 slots (lz_bin_tree.go:139-143) and the first
+//      6 and 8 bytes of every position;
 //   2. stable radix sorts of (key, position) -- rocPRIM device radix sort, the one
-//      library primitive used -- giving each bucket's positions in ascending order;
-//   3. table kernels: 12-byte entries (position, 8 bytes of its text) in sorted order
-//      for the hash-4 buckets, the 8-gram groups and the 16-gram groups, and per
-//      position its rank and its group's start in each table and the previous
-//      position with the same hash-2 / hash-3 slot;
-//   4. the scan kernel (lzma_mf_core.hpp): one wave per position, 64 candidates per
-//      step read as consecutive 12-byte entries, record breakers by ballot.  Each
-//      wave walks a run of consecutive positions and appends their pairs to a
-//      private page of a global arena (one atomic per 8192 pairs); a word per
-//      position records where its pairs are.
+//      library primitive used -- giving each group's positions in ascending order.  The
+//      16-gram table needs no sort over 16 bytes: the positions in 8-gram order, each
+//      moved back by 8, are already ordered by their bytes 8..15, and one stable sort by
+//      the 8-gram group of bytes 0..7 (a 31-bit key) finishes the order;
+//   3. table kernels: 12-byte entries (position, 8 bytes of its text; a flag on the oldest
+//      entry of each group) in sorted order for the hash-4 buckets and the 6-, 8- and
+//      16-gram groups, and per position its rank in each table and the previous position
+//      with the same hash-2 / hash-3 slot;
+//   4. the scan kernel (lzma_mf_core.hpp): four positions per wave, one per 16-lane row,
+//      16 candidates of every level per step, record breakers by a prefix maximum over the
+//      row.  The loads of a position (its record, then the newest entries of its groups)
+//      are issued one and two positions ahead of the position being worked on.  Each row
+//      walks a run of consecutive positions and appends their pairs to a private page of a
+//      global arena (one atomic per 4096 pairs); a word per position records where its
+//      pairs are.
 //   5. (stand-alone entry point only) an exclusive scan of the counts and a gather
 //      put the pairs in position order.
 //
@@ -33,13 +37,13 @@
 
 namespace {
 
+using lz::kMfFirst;
 using lz::kNone;
 using lz::MfEnt;
 using lz::MfInfo;
 
-enum { KEY2 = 2, KEY3 = 3, KEY4 = 4, KEY8 = 8 };
+enum { KEY2 = 2, KEY3 = 3, KEY4 = 4, KEY6 = 6, KEY8 = 8 };
 
-// KEY8: mask is the byte offset of the 8 bytes taken as the key
 template <int KIND, class K>
 __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      uint32_t mask, K *__restrict__ keys) {
@@ -48,9 +52,11 @@ __global__ __launch_bounds__(256) void mf_key_kernel(const uint8_t *__restrict__
     __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t w = lz::mf_load8(data, n, KIND == KEY8 ? i + mask : i);
+        const uint64_t w = lz::mf_load8(data, n, i);
         if (KIND == KEY8) {
             keys[i] = (K)w;
+        } else if (KIND == KEY6) {
+            keys[i] = (K)(w & 0xFFFFFFFFFFFFull);
         } else {
             const uint32_t b0 = w & 0xFF, b1 = (w >> 8) & 0xFF, b2 = (w >> 16) & 0xFF,
                            b3 = (w >> 24) & 0xFF;
@@ -77,39 +83,67 @@ __global__ __launch_bounds__(256) void mf_head_kernel(const K *__restrict__ skey
         head[j] = (j > 0 && skey[j - 1] != skey[j]) ? j : 0;
 }
 
-// 16-gram key of position i: the 8-gram group of i and the 8-gram group of i + 8 (a group's
-// start index in the 8-gram table names it), so that one sort orders the positions by their
-// first 16 bytes.  The last 8 positions of the text get keys of their own: no search looks at
-// them (a search at level 16 needs 16 bytes after its position and only meets older ones).
-__global__ __launch_bounds__(256) void mf_key16_kernel(const MfInfo *__restrict__ info, uint32_t n,
-                                                       uint64_t *__restrict__ keys) {
+// gid[ord[j]] = start of the group entry j belongs to: a number that names the 8-gram of a position
+__global__ __launch_bounds__(256) void mf_gid_kernel(const uint32_t *__restrict__ ord,
+                                                     const uint32_t *__restrict__ gstart, uint32_t n,
+                                                     uint32_t *__restrict__ gid) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t hi = info[i].g8;
-        const uint32_t lo = i + 8 < n ? info[i + 8].g8 : (0x80000000u | i);
-        keys[i] = ((uint64_t)hi << 32) | lo;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) gid[ord[j]] = gstart[j];
+}
+
+// Input of the 16-gram sort.  ord8 holds the positions ordered by (bytes 0..7, position);
+// position p - 8 has p's bytes 0..7 as its bytes 8..15, so the sequence p - 8 is ordered by
+// (bytes 8..15, position), and a stable sort of it by the 8-gram group of bytes 0..7 orders it
+// by the first 16 bytes.  The eight positions at the end of the text, which have no position
+// eight ahead, take the places of p = 0..7 with keys of their own: no search looks at them
+// (a search at level 16 needs 16 bytes after its position and only meets older ones).
+__global__ __launch_bounds__(256) void mf_shift16_kernel(const uint32_t *__restrict__ ord8,
+                                                         const uint32_t *__restrict__ gid8, uint32_t n,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t p = ord8[j];
+        if (p >= 8) {
+            keys[j] = gid8[p - 8];
+            vals[j] = p - 8;
+        } else {
+            keys[j] = n + p;
+            vals[j] = n - 8 + p;
+        }
     }
 }
 
-// ent[j] = {ord[j], 8 bytes at data[ord[j] + sig_off]};  rank of ord[j] = j, its group starts at gstart[j]
-template <int WHICH>
+// Keys that tell the 16-gram groups apart in the sorted order: (8-gram group of the position,
+// 8-gram group of the position + 8), the latter replaced by a number of its own for the last
+// eight positions of the text.
+__global__ __launch_bounds__(256) void mf_key16_kernel(const uint32_t *__restrict__ ord,
+                                                       const uint32_t *__restrict__ gid8, uint32_t n,
+                                                       uint64_t *__restrict__ keys) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint32_t i = ord[j];
+        const uint32_t lo = i + 8 < n ? gid8[i + 8] : (0x80000000u | i);
+        keys[j] = ((uint64_t)gid8[i] << 32) | lo;
+    }
+}
+
+// ent[j] = {ord[j] (flagged if it is the oldest of its group), 8 bytes at data[ord[j] + sig_off]};
+// rank of ord[j] = j, flagged the same way
+template <int LEVEL, class K>
 __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      const uint32_t *__restrict__ ord,
-                                                     const uint32_t *__restrict__ gstart,
-                                                     uint32_t sig_off, MfEnt *__restrict__ ent,
-                                                     MfInfo *__restrict__ info) {
+                                                     const K *__restrict__ skey, uint32_t sig_off,
+                                                     MfEnt *__restrict__ ent, MfInfo *__restrict__ info) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t p = ord[j];
+        const uint32_t first = (j == 0 || skey[j - 1] != skey[j]) ? kMfFirst : 0u;
         const uint64_t sig = lz::mf_load8(data, n, p + sig_off);
         MfEnt e;
-        e.pos = p;
+        e.pos = p | first;
         e.sig_lo = (uint32_t)sig, e.sig_hi = (uint32_t)(sig >> 32);
         ent[j] = e;
-        const uint32_t g = gstart[j];
-        if (WHICH == 4) info[p].rank4 = j, info[p].g4 = g;
-        else if (WHICH == 8) info[p].rank8 = j, info[p].g8 = g;
-        else info[p].rank16 = j, info[p].g16 = g;
+        info[p].rank[LEVEL] = j | first;
     }
 }
 
@@ -183,6 +217,12 @@ int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, 
     return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st)
                    : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
 }
+// values out = vals_in ordered by key (stable)
+int sort_vals_by_key(lzh::MfScratch &s, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
+                     uint32_t *vals_out, uint32_t n, unsigned end_bit, hipStream_t st) {
+    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st)
+                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
+}
 
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
     size_t bytes = 0;
@@ -193,9 +233,9 @@ int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
     return LZMA_AMD_OK;
 }
 
-unsigned bits_of(uint32_t mask) {
+unsigned bits_of(uint64_t mask) {
     unsigned b = 0;
-    while (b < 32 && (mask >> b) != 0) b++;
+    while (b < 64 && (mask >> b) != 0) b++;
     return b ? b : 1;
 }
 
@@ -206,8 +246,11 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 //
 // Each row of a wave walks its own run of consecutive positions and appends their pairs to
 // a private page of the arena (one atomic per page); the result word of a position says
-// where its pairs are.
-__global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+// where its pairs are.  The walk is software-pipelined: while position k is worked on, the
+// newest table entries of position k + 1 and the record and text of position k + 2 are on
+// their way, so a position's two dependent memory round trips overlap the work on the two
+// before it.
+__global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
@@ -237,17 +280,22 @@ __global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const ui
             job = lo;
             js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
         }
+        // pipeline prologue: positions 0 and 1 of the run
+        lz::MfPos a_cur, a_next;
+        lz::MfFront f_cur;
+        lz::mf_load_pos(t, p_begin, row_on && p_begin < p_end, a_cur);
+        lz::mf_load_front(t, a_cur, row_on && p_begin < p_end, idx, f_cur);
+        lz::mf_load_pos(t, p_begin + 1, row_on && p_begin + 1 < p_end, a_next);
         for (uint32_t k = 0; k < kRowRun; k++) {
             const uint32_t P = p_begin + k;
             const bool act = row_on && P < p_end;
             if (!__any(act)) break;
-            lz::MfInfo inf = {};
-            if (act) inf = t.info[P];
-            uint64_t p0 = 0, p8 = 0, p16 = 0;  // bytes 0..7, 8..15, 16..23 at P
-            if (act) {
-                p0 = lz::mf_load8(t.data, n, P), p8 = lz::mf_load8(t.data, n, P + 8);
-                p16 = lz::mf_load8(t.data, n, P + 16);
-            }
+            // entries of position k + 1 (its record has had a whole step to arrive), then the
+            // record of position k + 2
+            lz::MfFront f_next;
+            lz::mf_load_front(t, a_next, row_on && P + 1 < p_end, idx, f_next);
+            lz::MfPos a_next2;
+            lz::mf_load_pos(t, P + 2, row_on && P + 2 < p_end && k + 2 < kRowRun, a_next2);
             if (act)
                 while (P >= je) {  // empty jobs are skipped
                     job++;
@@ -271,14 +319,18 @@ __global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const ui
                 }
             }
             lz::MfRowOut out;
-            out.dst = arena + 2 * cursor;
+            out.packed = t.packed != 0;
+            out.dst = arena + (out.packed ? cursor : 2 * cursor);
             out.on = act && !overflow;
-            const uint32_t c = lz::mf_find4(t, P, inf, p0, p8, p16, js, je, act, out, lane);
+            const uint32_t c = lz::mf_find4(t, P, a_cur, f_cur, js, je, act, out, lane);
             if (act) {
                 if (idx == 0) meta[P] = lz::mf_meta(cursor, c);
                 if (!overflow) cursor += c;
                 emitted += c;
             }
+            a_cur = a_next;
+            f_cur = f_next;
+            a_next = a_next2;
         }
     }
     if (idx == 0) {
@@ -291,13 +343,22 @@ __global__ __launch_bounds__(64, 8) void mf_scan_kernel(lz::MfTables t, const ui
 __global__ __launch_bounds__(256) void mf_gather_kernel(const uint64_t *__restrict__ meta,
                                                         const uint32_t *__restrict__ arena, uint32_t n,
                                                         const uint64_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ pairs, uint64_t pairs_cap) {
+                                                        uint32_t *__restrict__ pairs, uint64_t pairs_cap,
+                                                        uint32_t packed) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t P = blockIdx.x * blockDim.x + threadIdx.x; P < n; P += stride) {
         const uint64_t m = meta[P], src = lz::mf_meta_off(m), dst = offsets[P];
         const uint32_t c = lz::mf_meta_count(m);
         if (dst + c > pairs_cap) continue;
-        for (uint32_t k = 0; k < 2 * c; k++) pairs[2 * dst + k] = arena[2 * src + k];
+        if (packed) {
+            for (uint32_t k = 0; k < c; k++) {
+                const uint32_t w = arena[src + k];
+                pairs[2 * (dst + k)] = lz::mf_pack_len(w);
+                pairs[2 * (dst + k) + 1] = lz::mf_pack_dist(w);
+            }
+        } else {
+            for (uint32_t k = 0; k < 2 * c; k++) pairs[2 * dst + k] = arena[2 * src + k];
+        }
     }
 }
 
@@ -322,6 +383,13 @@ static size_t lib_temp_bytes_cfg(uint32_t n) {
     t = std::max(t, sort_temp_bytes<Cfg, uint64_t>(n, 64));
     {
         size_t b = 0;
+        (void)rocprim::radix_sort_pairs<Cfg>(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32,
+                                             (hipStream_t) nullptr);
+        t = std::max(t, b);
+    }
+    {
+        size_t b = 0;
         (void)rocprim::radix_sort_pairs<Cfg>(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                              (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64,
                                              (hipStream_t) nullptr);
@@ -337,15 +405,13 @@ static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or sc
 
 size_t MfScratch::tmp_bytes(uint32_t n) {
     const size_t n1 = n ? n : 1;
-    return 2 * align256(n1 * 8) + 2 * align256(n1 * 4) + align256(lib_temp_bytes((uint32_t)n1));
+    return 2 * align256(n1 * 8) + 3 * align256(n1 * 4) + align256(lib_temp_bytes((uint32_t)n1));
 }
 
 int MfScratch::reserve(uint32_t n) {
     if (n <= cap && cap != 0) return LZMA_AMD_OK;
     const size_t n1 = n ? n : 1;
-    LZ_HIP(ent4.alloc(n1 * sizeof(MfEnt)));
-    LZ_HIP(ent8.alloc(n1 * sizeof(MfEnt)));
-    LZ_HIP(ent16.alloc(n1 * sizeof(MfEnt)));
+    for (auto &e : ent) LZ_HIP(e.alloc(n1 * sizeof(MfEnt)));
     LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
     cap = (uint32_t)n1;
     return LZMA_AMD_OK;
@@ -366,72 +432,76 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
         kout = q, q += align256(n1 * 8);
         vout = q, q += align256(n1 * 4);
         grp = q, q += align256(n1 * 4);
+        gid = q, q += align256(n1 * 4);
         temp = q;
         temp_bytes = need - (size_t)(q - (uint8_t *)tmp);
     }
     const uint32_t mask = lz::bt4_hash_mask(dict_size);
     view.data = d_data;
     view.n = n;
-    view.ent4 = ent4.as<MfEnt>();
-    view.ent8 = ent8.as<MfEnt>();
-    view.ent16 = ent16.as<MfEnt>();
+    for (uint32_t l = 0; l < lz::kMfLevels; l++) view.ent[l] = ent[l].as<MfEnt>();
     view.info = info.as<MfInfo>();
     view.dict = dict_size;
     view.fb = fb;
-    view.use8 = fb >= 8;
-    view.use16 = fb >= 16;
+    view.levels = 1;
+    while (view.levels < lz::kMfLevels && fb >= lz::mf_known(view.levels)) view.levels++;
+    if (n < 32) view.levels = 1;  // too short for any search to use the finer groups' shift by 8
+    view.packed = lz::mf_can_pack(dict_size) ? 1u : 0u;
     if (n == 0) return LZMA_AMD_OK;
 
     const unsigned g = grid_for(n, 256);
-    // hash-4 buckets
+    MfEnt *e0 = ent[0].as<MfEnt>(), *e1 = ent[1].as<MfEnt>(), *e2 = ent[2].as<MfEnt>(), *e3 = ent[3].as<MfEnt>();
+    MfInfo *inf = info.as<MfInfo>();
+    uint32_t *ord = (uint32_t *)vout;
+    // level 0: hash-4 buckets
     hipLaunchKernelGGL((mf_key_kernel<KEY4, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, mask,
                        (uint32_t *)kin);
-    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n,
-                          bits_of(mask), st)))
-        return rc;
-    hipLaunchKernelGGL(mf_head_kernel<uint32_t>, dim3(g), dim3(256), 0, st, (uint32_t *)kout, n,
-                       (uint32_t *)grp);
-    if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
-    hipLaunchKernelGGL(mf_ent_kernel<4>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
-                       (uint32_t *)grp, 0u, ent4.as<MfEnt>(), info.as<MfInfo>());
-    // 8-gram groups
-    if (view.use8) {
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, bits_of(mask), st))) return rc;
+    hipLaunchKernelGGL((mf_ent_kernel<0, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
+                       (const uint32_t *)kout, 0u, e0, inf);
+    // level 1: 6-gram groups
+    if (view.levels > 1) {
+        hipLaunchKernelGGL((mf_key_kernel<KEY6, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
+                           (uint64_t *)kin);
+        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 48, st))) return rc;
+        hipLaunchKernelGGL((mf_ent_kernel<1, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kout, 6u, e1, inf);
+    }
+    // level 2: 8-gram groups
+    if (view.levels > 2) {
         hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            (uint64_t *)kin);
-        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)vout, n, 64,
-                              st)))
-            return rc;
-        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (uint64_t *)kout, n,
-                           (uint32_t *)grp);
-        if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
-        hipLaunchKernelGGL(mf_ent_kernel<8>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
-                           (uint32_t *)grp, 8u, ent8.as<MfEnt>(), info.as<MfInfo>());
+        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 64, st))) return rc;
+        hipLaunchKernelGGL((mf_ent_kernel<2, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kout, 8u, e2, inf);
     }
-    // 16-gram groups: one sort by (8-gram group of the position, 8-gram group of the position + 8),
-    // both known from the table just built (fb >= 16 implies the 8-gram table)
-    if (view.use16) {
-        hipLaunchKernelGGL(mf_key16_kernel, dim3(g), dim3(256), 0, st, info.as<MfInfo>(), n, (uint64_t *)kin);
-        if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, (uint32_t *)vout, n, 64, st)))
-            return rc;
-        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (uint64_t *)kout, n,
+    // level 3: 16-gram groups, from the 8-gram order (see mf_shift16_kernel)
+    if (view.levels > 3) {
+        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (const uint64_t *)kout, n,
                            (uint32_t *)grp);
         if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
-        hipLaunchKernelGGL(mf_ent_kernel<16>, dim3(g), dim3(256), 0, st, d_data, n, (uint32_t *)vout,
-                           (uint32_t *)grp, 16u, ent16.as<MfEnt>(), info.as<MfInfo>());
+        hipLaunchKernelGGL(mf_gid_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)grp, n, (uint32_t *)gid);
+        // keys and values of the sort share the key-input area (32-bit keys leave half of it free)
+        uint32_t *k16 = (uint32_t *)kin, *v16 = (uint32_t *)kin + n;
+        hipLaunchKernelGGL(mf_shift16_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n, k16, v16);
+        // the sorted keys name the 16-gram groups only together with the bytes 8..15 order, so the
+        // group boundaries are found from the pair (key, 8-gram group of the position + 8) below
+        if ((rc = sort_vals_by_key(*this, k16, (uint32_t *)kout, v16, ord, n, bits_of((uint64_t)n + 8), st)))
+            return rc;
+        hipLaunchKernelGGL(mf_key16_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n,
+                           (uint64_t *)kin);
+        hipLaunchKernelGGL((mf_ent_kernel<3, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kin, 16u, e3, inf);
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        (uint32_t *)kin);
-    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n, 16, st)))
-        return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, (uint32_t *)vout,
-                       (uint32_t *)kout, n, info.as<MfInfo>());
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, 16, st))) return rc;
+    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf);
     hipLaunchKernelGGL((mf_key_kernel<KEY2, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        (uint32_t *)kin);
-    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, (uint32_t *)vout, n, 10, st)))
-        return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, (uint32_t *)vout,
-                       (uint32_t *)kout, n, info.as<MfInfo>());
+    if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, 10, st))) return rc;
+    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf);
     LZ_HIP(hipGetLastError());
     return LZMA_AMD_OK;
 }
@@ -443,8 +513,9 @@ static unsigned scan_blocks(uint32_t n) {
     return blocks ? blocks : 1;
 }
 
-int MfResult::reserve(uint32_t n) {
-    if (n <= cap && cap != 0) return LZMA_AMD_OK;
+int MfResult::reserve(uint32_t n, uint32_t pair_bytes_) {
+    if (n <= cap && cap != 0 && pair_bytes_ <= pair_bytes) return LZMA_AMD_OK;
+    pair_bytes = pair_bytes_;
     const size_t n1 = n ? n : 1;
     LZ_HIP(meta.alloc(n1 * 8));
     LZ_HIP(ctrl.alloc(3 * 8));
@@ -455,7 +526,7 @@ int MfResult::reserve(uint32_t n) {
     const char *tiny = getenv("LZMA_AMD_ARENA_TEST");
     const uint64_t rows = (uint64_t)scan_blocks((uint32_t)n1) * 16;
     const uint64_t want = (tiny && tiny[0] == '1') ? rows * kMfPagePairs / 2 : (uint64_t)n1 * 5 + rows * kMfPagePairs;
-    LZ_HIP(arena.alloc(want * 8));
+    LZ_HIP(arena.alloc(want * pair_bytes));
     arena_pairs = want;
     cap = (uint32_t)n1;
     return LZMA_AMD_OK;
@@ -469,8 +540,11 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
         LZ_HIP(hipStreamSynchronize(st));
         return LZMA_AMD_OK;
     }
-    int rc = r.reserve(n);
+    const uint32_t pair_bytes = s.view.packed ? 4u : 8u;
+    int rc = r.reserve(n, pair_bytes);
     if (rc) return rc;
+    // an arena kept from a call with one-word pairs holds half as many two-word pairs
+    r.arena_pairs = r.arena.bytes / pair_bytes;
     const unsigned blocks = scan_blocks(n);
     const uint64_t nrows = (uint64_t)blocks * 16;  // 16-lane rows, each with an arena page of its own
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -492,7 +566,7 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
         if (const char *tiny = getenv("LZMA_AMD_ARENA_TEST"))
             if (tiny[0] == '1') fprintf(stderr, "lzma_amd: arena grown to %llu pairs\n", (unsigned long long)want);
         LZ_HIP(hipDeviceSynchronize());
-        LZ_HIP(r.arena.alloc(want * 8));
+        LZ_HIP(r.arena.alloc(want * pair_bytes));
         r.arena_pairs = want;
     }
     return fail(LZMA_AMD_ERR_NOMEM, "match finder arena kept overflowing");
@@ -580,7 +654,7 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
         if (d_offsets) LZ_HIP(hipMemcpyAsync(d_offsets, offs.p, n * 8, hipMemcpyDeviceToDevice, st));
         if (d_pairs && total <= pairs_cap)
             hipLaunchKernelGGL(mf_gather_kernel, dim3(g), dim3(256), 0, st, res.d_meta(), res.d_arena(), N,
-                               offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap);
+                               offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap, ws.view.packed);
     }
     t_all.stop();
     LZ_HIP(hipGetLastError());

@@ -17,12 +17,12 @@ namespace lzh {
 constexpr uint32_t kMfPagePairs = 4096;  // arena page: pairs a 16-lane row appends to before taking a new page
 
 struct MfScratch {
-    DevBuf ent4, ent8, ent16, info; // tables (see lzma_mf_core.hpp)
+    DevBuf ent[lz::kMfLevels], info; // tables (see lzma_mf_core.hpp)
     DevBuf own_tmp;                 // temporaries, when the caller lends no memory for them
     uint32_t cap = 0;               // positions the tables hold
     lz::MfTables view;
     // temporaries of one build: sort keys in/out, sorted positions, group starts, library scratch
-    void *kin = nullptr, *kout = nullptr, *vout = nullptr, *grp = nullptr, *temp = nullptr;
+    void *kin = nullptr, *kout = nullptr, *vout = nullptr, *grp = nullptr, *gid = nullptr, *temp = nullptr;
     size_t temp_bytes = 0;
     // No encode kernel is resident while this build's sorts run: they may use the library's
     // single-pass radix sort (see matchfinder.hip).  Set by the caller before build().
@@ -31,6 +31,12 @@ struct MfScratch {
     int reserve(uint32_t n);
     // Bytes of temporaries a build of n positions needs.
     static size_t tmp_bytes(uint32_t n);
+    // Makes sure builds of up to n positions find their temporaries without allocating.
+    int reserve_tmp(uint32_t n) {
+        const size_t need = tmp_bytes(n);
+        if (own_tmp.bytes < need) LZ_HIP(own_tmp.alloc(need));
+        return LZMA_AMD_OK;
+    }
     // Builds every table for d_data[0..n) on `st`; no host synchronization.  dict_size/fb as
     // given to the reference's newLzBinTree (lz_bin_tree.go:35).  The temporaries go to
     // tmp[0..tmp_cap) if that is large enough (memory that is dead until the scan, such as the
@@ -38,16 +44,28 @@ struct MfScratch {
     int build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st,
               void *tmp = nullptr, size_t tmp_cap = 0);
     void release() {
-        ent4.release(), ent8.release(), ent16.release(), info.release(), own_tmp.release();
+        for (auto &e : ent) e.release();
+        info.release(), own_tmp.release();
         cap = 0;
+    }
+    uint64_t bytes() const {
+        uint64_t b = info.bytes + own_tmp.bytes;
+        for (const auto &e : ent) b += e.bytes;
+        return b;
+    }
+    // table bytes per position (temporaries not included)
+    static uint64_t bytes_per_position(uint32_t fb) {
+        (void)fb;
+        return lz::kMfLevels * sizeof(lz::MfEnt) + sizeof(lz::MfInfo);
     }
 };
 
 struct MfResult {
-    DevBuf meta, arena, ctrl;  // meta[n] (u64), arena of (len, dist-1) u32 pairs, control words
+    DevBuf meta, arena, ctrl;  // meta[n] (u64), arena of (len, dist-1) pairs (two words or one packed), control words
     uint64_t arena_pairs = 0;
     uint32_t cap = 0;
-    int reserve(uint32_t n);
+    uint32_t pair_bytes = 8;  // 4 when the pairs are packed into one word (lz::mf_pack)
+    int reserve(uint32_t n, uint32_t pair_bytes);
     void release() {
         meta.release(), arena.release(), ctrl.release();
         arena_pairs = 0, cap = 0;
