@@ -357,6 +357,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
 
     lzh::release_finder_workspace();  // what a match-finder call of this thread kept is needed here
     int enc_streams = kEncStreams;
+    const bool sort_alone = getenv("LZMA_AMD_SORT_ALONE") != nullptr;  // experiment: single-pass sorts next to encode launches
     if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
     // with many chunks a batch holds the resident workgroups' share of one launch, so that
     // the launches in flight fill the device exactly; few or small chunks are batched by size
@@ -468,7 +469,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         t_mf[b].start(S.mf);
         // the sort temporaries live in the arena the scan is about to fill when it is large
         // enough; the first batch's sorts run before any encode launch of this call
-        scratch.alone = b == 0;
+        scratch.alone = b == 0 || sort_alone;
         if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
                                 sl.res.arena.bytes)))
             return bail(rc);

@@ -37,14 +37,31 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMfLevels = 4;
 // bytes the members of a level's group are known to share
 LZ_HD uint32_t mf_known(uint32_t level) { return level == 0 ? 0u : (level == 1 ? 6u : (level == 2 ? 8u : 16u)); }
-constexpr uint32_t kMfFirst = 0x80000000u;  // entry: oldest of its group; rank word: the position is
+constexpr uint32_t kMfFirst = 0x80000000u;  // entry: it is the oldest of its group
+// A position's rank word says how many older members its group has, so that a search fetches
+// no more entries than can be candidates: tables of up to 2^30 entries keep a class in bits
+// 30..31 (0: none, 1: one or two, 2: three or four, 3: more), larger ones a flag in bit 31
+// (set: none).
+constexpr uint32_t kMfClassMax = 1u << 30;
+LZ_HD uint32_t mf_rank_word(uint32_t rank, uint32_t older_capped5, bool wide) {
+    if (wide) return rank | (older_capped5 == 0 ? 0x80000000u : 0u);
+    const uint32_t cls = older_capped5 == 0 ? 0u : (older_capped5 <= 2 ? 1u : (older_capped5 <= 4 ? 2u : 3u));
+    return rank | (cls << 30);
+}
+LZ_HD uint32_t mf_rank_of(uint32_t w, bool wide) { return wide ? (w & 0x7FFFFFFFu) : (w & 0x3FFFFFFFu); }
+// entries worth fetching below the position's own (0: it is the oldest of its group)
+LZ_HD uint32_t mf_rank_fetch(uint32_t w, bool wide) {
+    if (wide) return (w >> 31) ? 0u : 16u;
+    const uint32_t cls = w >> 30;
+    return cls == 0 ? 0u : (cls == 1 ? 2u : (cls == 2 ? 4u : 16u));
+}
 
 // One entry of a sorted table: a position (bit 31: it is the oldest of its group) and the 8
 // bytes of its text that follow the bytes the group shares.
 struct MfEnt {
     uint32_t pos, sig_lo, sig_hi;
 };
-// Per position: its index in each level's table (bit 31: it is the oldest of its group there)
+// Per position: its rank word in each level's table (mf_rank_word)
 // and the previous position with the same hash-2 / hash-3 slot if it starts with the same byte
 // (kNone otherwise).
 struct __attribute__((aligned(16))) MfInfo {
@@ -59,6 +76,7 @@ struct MfTables {
     const MfInfo *info;
     uint32_t dict, fb;
     uint32_t levels;      // levels built (1 + those whose known bytes do not exceed fb)
+    uint32_t wide;        // more than 2^30 positions: rank words carry a flag instead of a class
     uint32_t packed;      // pairs are written as one word each (mf_pack) instead of two
 };
 
@@ -104,6 +122,22 @@ LZ_D uint32_t mf_extend(const uint8_t *data, uint32_t n, uint32_t P, uint32_t Q,
     }
     return l < limit ? l : limit;
 }
+
+// Section timing for diagnostic builds (-DMF_PROFILE): MF_LAP(i) charges the cycles since the
+// previous lap to section i of the wave's counters.  Compiled out otherwise.
+#if defined(MF_PROFILE)
+struct MfProf {
+    uint64_t t[8], last;
+};
+__device__ MfProf *g_mf_prof_;  // set per wave by the kernel
+#define MF_PROF_ARG , MfProf &pf
+#define MF_PROF_PASS , pf
+#define MF_LAP(i) { const uint64_t t_ = __builtin_readcyclecounter(); pf.t[i] += t_ - pf.last; pf.last = t_; }
+#else
+#define MF_PROF_ARG
+#define MF_PROF_PASS
+#define MF_LAP(i)
+#endif
 
 LZ_D uint32_t mf_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 LZ_D uint64_t mf_u64(uint64_t v) { return ((uint64_t)mf_u32((uint32_t)(v >> 32)) << 32) | mf_u32((uint32_t)v); }
@@ -174,30 +208,34 @@ LZ_D void mf_load_front(const MfTables &t, const MfPos &a, bool act, uint32_t id
 #pragma unroll
     for (uint32_t l = 0; l < kMfLevels; l++) {
         f.e[l].pos = 0, f.e[l].sig_lo = 0, f.e[l].sig_hi = 0;
-        const uint32_t r = a.inf.rank[l];
+        const uint32_t w = a.inf.rank[l], r = mf_rank_of(w, t.wide != 0);
         // the rank words of levels that were not built are never looked at
-        if (act && l < t.levels && !(r & kMfFirst) && idx < r) f.e[l] = t.ent[l][r - 1 - idx];
+        if (act && l < t.levels && idx < mf_rank_fetch(w, t.wide != 0) && idx < r) f.e[l] = t.ent[l][r - 1 - idx];
     }
 }
 
 // One level of the scan for every row that has `go` set: entries tab[top-1], tab[top-2],
 // ... newest first, down to the oldest of the position's group and as long as their
 // position is >= low.  `first` holds the 16 newest (lane k of the row: entry top-1-k),
-// fetched by the caller.  Candidate lengths are `known` + the bytes sig shares with psig,
+// fetched by the caller (only the first `fetched` of them where the group is known to be
+// that small).  Candidate lengths are `known` + the bytes sig shares with psig,
 // continued in the window beyond known+8 if `deep`.  A candidate is reported if it is
 // longer than everything newer.  Sets fin where a match of len_limit ended the whole search.
 //
 // Most scans end within the first 16 candidates: that step runs for the four rows at once,
 // every lane writing its own pair.  A row that has to go on does so with all 64 lanes of
 // the wave, one such row after the other.
-LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, const MfEnt &first, uint32_t low,
-                   uint64_t psig, uint32_t known, bool deep, uint32_t P, uint32_t len_limit, uint32_t &n,
-                   uint32_t &max_len, bool &fin, bool go, const MfRowOut &out, uint32_t lane) {
+LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t fetched, const MfEnt &first, uint32_t low,
+                   uint64_t psig, uint32_t known, bool deep, uint32_t P, uint32_t len_limit, uint32_t ceil,
+                   uint32_t &n, uint32_t &max_len, bool &fin, bool go, const MfRowOut &out, uint32_t lane MF_PROF_ARG) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
-    go = go && !fin && top != 0;
+    // no candidate of this level is longer than `ceil` (all that share more are in the next
+    // level's group): once a match that long is found the level has nothing more to report
+    go = go && !fin && top != 0 && max_len < ceil;
     if (!__any(go)) return;
     {   // ---- first step, four rows at once
-        const bool inb = go && idx < top;
+        // `fetched` < 16 entries were fetched where the group is known to have no more older members
+        const bool inb = go && idx < top && idx < fetched;
         // an entry that is the oldest of its group ends the group: older ones are not candidates
         const uint32_t ends = row_ballot(inb && (first.pos & kMfFirst) != 0, row_base);
         bool valid = inb && (ends & ((1u << idx) - 1u)) == 0;
@@ -227,15 +265,16 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, const MfEn
             if (max_len == len_limit && m != 0) fin = true;  // lz_bin_tree.go:231-235
         }
         // go on only if every entry of this step was a candidate and the group goes on
-        go = go && !fin && vm == 0xFFFFu && ends == 0 && top > 16;
+        go = go && !fin && vm == 0xFFFFu && ends == 0 && top > 16 && max_len < ceil;
     }
+    MF_LAP(2)
     // ---- rows that go on, one after the other, 64 candidates per step
     unsigned long long pending = __ballot(go && idx == 0);
     while (pending != 0) {
         const int src = __builtin_ctzll(pending);  // first lane of the row
         pending &= pending - 1;
         const uint32_t u_top = lane_get(top, src), u_low = lane_get(low, src);
-        const uint32_t u_P = lane_get(P, src), u_limit = lane_get(len_limit, src);
+        const uint32_t u_P = lane_get(P, src), u_limit = lane_get(len_limit, src), u_ceil = lane_get(ceil, src);
         const uint64_t u_sig = lane_get64(psig, src);
         uint32_t *u_dst = (uint32_t *)lane_get64((uint64_t)out.dst, src);
         const bool u_on = lane_get((uint32_t)out.on, src) != 0;
@@ -272,10 +311,11 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, const MfEn
                     break;
                 }
             }
-            if (__ballot(valid) != ~0ull || ends != 0) break;
+            if (__ballot(valid) != ~0ull || ends != 0 || u_max >= u_ceil) break;
         }
         if (row_base == (uint32_t)src) n = u_n, max_len = u_max, fin = fin || u_fin;
     }
+    MF_LAP(3)
 }
 
 // Match lists of four positions, one per row.  P, `a` (the position's record and text), `f`
@@ -284,7 +324,7 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, const MfEn
 // written through `out` (a later pair with a smaller index overwrites: the reference drops
 // seed pairs that way).
 LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFront &f, uint32_t job_start,
-                       uint32_t job_end, bool act, const MfRowOut &out, uint32_t lane) {
+                       uint32_t job_end, bool act, const MfRowOut &out, uint32_t lane MF_PROF_ARG) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
     const uint32_t left = act ? job_end - P : 0;
     const uint32_t len_limit = left < t.fb ? left : t.fb;
@@ -299,15 +339,16 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFr
 
     // per level: the position's rank, whether it has an older member of its group at all, and
     // the newest such member
-    uint32_t top[kMfLevels], newest[kMfLevels];
+    uint32_t top[kMfLevels], newest[kMfLevels], fetched[kMfLevels];
     bool has[kMfLevels];
 #pragma unroll
     for (uint32_t l = 0; l < kMfLevels; l++) {
-        const uint32_t r = a.inf.rank[l];
+        const uint32_t w = a.inf.rank[l], r = mf_rank_of(w, t.wide != 0);
         // a level is used if it was built and the position has that many bytes to compare
         const bool use = act && l < t.levels && (l == 0 || len_limit >= mf_known(l));
-        has[l] = use && !(r & kMfFirst) && r != 0;
+        has[l] = use && mf_rank_fetch(w, t.wide != 0) != 0 && r != 0;
         top[l] = has[l] ? r : 0u;
+        fetched[l] = mf_rank_fetch(w, t.wide != 0);
         newest[l] = row_first(f.e[l].pos, row_base) & ~kMfFirst;
     }
     uint32_t q4 = kNone;
@@ -332,6 +373,7 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFr
         max_len = 1;
     }
 
+    MF_LAP(1)
     // each level down to the newest in-window member of the next level's group
     bool fin = false;
     bool go[kMfLevels];
@@ -345,8 +387,11 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFr
         else if (l == 1) psig = (a.p0 >> 48) | (a.p8 << 16);
         else if (l == 2) psig = a.p8;
         else psig = a.p16;
-        mf_level(t, t.ent[l], top[l], f.e[l], low, psig, mf_known(l), l + 1 == kMfLevels, P, len_limit, n, max_len,
-                 fin, go[l], out, lane);
+        // candidates of this level share fewer bytes than the next level's groups do
+        const uint32_t ceil = (l + 1 < kMfLevels && l + 1 < t.levels && len_limit >= mf_known(l + 1))
+                                  ? mf_known(l + 1) - 1 : len_limit;
+        mf_level(t, t.ent[l], top[l], fetched[l], f.e[l], low, psig, mf_known(l), l + 1 == kMfLevels, P, len_limit, ceil,
+                 n, max_len, fin, go[l], out, lane MF_PROF_PASS);
     }
     return n;
 }

@@ -133,17 +133,23 @@ template <int LEVEL, class K>
 __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      const uint32_t *__restrict__ ord,
                                                      const K *__restrict__ skey, uint32_t sig_off,
-                                                     MfEnt *__restrict__ ent, MfInfo *__restrict__ info) {
+                                                     MfEnt *__restrict__ ent, MfInfo *__restrict__ info,
+                                                     uint32_t wide) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t p = ord[j];
-        const uint32_t first = (j == 0 || skey[j - 1] != skey[j]) ? kMfFirst : 0u;
+        const K key = skey[j];
+        // older members of the group, as far as the rank word tells them apart (the keys are
+        // sorted: an equal key k places down means k equal keys in between)
+        uint32_t older = 0;
+        if (j >= 1 && skey[j - 1] == key) older = (j >= 3 && skey[j - 3] == key) ? ((j >= 5 && skey[j - 5] == key) ? 5u : 3u) : 1u;
+        const uint32_t first = older == 0 ? kMfFirst : 0u;
         const uint64_t sig = lz::mf_load8(data, n, p + sig_off);
         MfEnt e;
         e.pos = p | first;
         e.sig_lo = (uint32_t)sig, e.sig_hi = (uint32_t)(sig >> 32);
         ent[j] = e;
-        info[p].rank[LEVEL] = j | first;
+        info[p].rank[LEVEL] = lz::mf_rank_word(j, older, wide != 0);
     }
 }
 
@@ -250,7 +256,10 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 // newest table entries of position k + 1 and the record and text of position k + 2 are on
 // their way, so a position's two dependent memory round trips overlap the work on the two
 // before it.
-__global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+#ifndef MF_SCAN_WAVES
+#define MF_SCAN_WAVES 4  // 112 registers, no spills: faster than more waves that spill
+#endif
+__global__ __launch_bounds__(64, MF_SCAN_WAVES) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
@@ -264,6 +273,10 @@ __global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const ui
     uint64_t cursor = 0, page_end = 0;  // the row's arena page
     uint64_t emitted = 0;
     bool overflow = false;
+#if defined(MF_PROFILE)
+    lz::MfProf pf = {};
+    pf.last = __builtin_readcyclecounter();
+#endif
     for (uint32_t run = wave; run < nruns; run += nwaves) {
         const uint32_t p_begin = run * kRun + row * kRowRun;
         uint32_t p_end = p_begin + kRowRun;
@@ -290,6 +303,7 @@ __global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const ui
             const uint32_t P = p_begin + k;
             const bool act = row_on && P < p_end;
             if (!__any(act)) break;
+            MF_LAP(4)
             // entries of position k + 1 (its record has had a whole step to arrive), then the
             // record of position k + 2
             lz::MfFront f_next;
@@ -318,11 +332,12 @@ __global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const ui
                     }
                 }
             }
+            MF_LAP(0)
             lz::MfRowOut out;
             out.packed = t.packed != 0;
             out.dst = arena + (out.packed ? cursor : 2 * cursor);
             out.on = act && !overflow;
-            const uint32_t c = lz::mf_find4(t, P, a_cur, f_cur, js, je, act, out, lane);
+            const uint32_t c = lz::mf_find4(t, P, a_cur, f_cur, js, je, act, out, lane MF_PROF_PASS);
             if (act) {
                 if (idx == 0) meta[P] = lz::mf_meta(cursor, c);
                 if (!overflow) cursor += c;
@@ -337,6 +352,12 @@ __global__ __launch_bounds__(64, 5) void mf_scan_kernel(lz::MfTables t, const ui
         if (overflow) atomicAdd(&ctrl[1], 1ull);
         atomicAdd(&ctrl[2], (unsigned long long)emitted);
     }
+#if defined(MF_PROFILE)
+    if (wave == 7 && lane == 0)
+        printf("MFPROF wave 7: issue-loads+page %llu | find setup %llu | first steps %llu | deep steps %llu | loop+meta %llu\n",
+               (unsigned long long)pf.t[0], (unsigned long long)pf.t[1], (unsigned long long)pf.t[2],
+               (unsigned long long)pf.t[3], (unsigned long long)pf.t[4]);
+#endif
 }
 
 // Stand-alone entry point: pairs of position P to out[offsets[P]...] in position order.
@@ -447,6 +468,7 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
     while (view.levels < lz::kMfLevels && fb >= lz::mf_known(view.levels)) view.levels++;
     if (n < 32) view.levels = 1;  // too short for any search to use the finer groups' shift by 8
     view.packed = lz::mf_can_pack(dict_size) ? 1u : 0u;
+    view.wide = n > lz::kMfClassMax ? 1u : 0u;
     if (n == 0) return LZMA_AMD_OK;
 
     const unsigned g = grid_for(n, 256);
@@ -458,14 +480,14 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
                        (uint32_t *)kin);
     if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, bits_of(mask), st))) return rc;
     hipLaunchKernelGGL((mf_ent_kernel<0, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                       (const uint32_t *)kout, 0u, e0, inf);
+                       (const uint32_t *)kout, 0u, e0, inf, view.wide);
     // level 1: 6-gram groups
     if (view.levels > 1) {
         hipLaunchKernelGGL((mf_key_kernel<KEY6, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            (uint64_t *)kin);
         if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 48, st))) return rc;
         hipLaunchKernelGGL((mf_ent_kernel<1, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kout, 6u, e1, inf);
+                           (const uint64_t *)kout, 6u, e1, inf, view.wide);
     }
     // level 2: 8-gram groups
     if (view.levels > 2) {
@@ -473,7 +495,7 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
                            (uint64_t *)kin);
         if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 64, st))) return rc;
         hipLaunchKernelGGL((mf_ent_kernel<2, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kout, 8u, e2, inf);
+                           (const uint64_t *)kout, 8u, e2, inf, view.wide);
     }
     // level 3: 16-gram groups, from the 8-gram order (see mf_shift16_kernel)
     if (view.levels > 3) {
@@ -491,7 +513,7 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
         hipLaunchKernelGGL(mf_key16_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n,
                            (uint64_t *)kin);
         hipLaunchKernelGGL((mf_ent_kernel<3, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kin, 16u, e3, inf);
+                           (const uint64_t *)kin, 16u, e3, inf, view.wide);
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
