@@ -144,6 +144,21 @@ int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, siz
                               uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
                               int32_t *d_status, void *stream);
 
+/* lzma_amd_decode_batch_dev for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, results and statuses as
+ * lzma_amd_decode_batch_dev, but what the kernels need beyond the caller's buffers (the
+ * workgroups' literal models, the list of streams with lc+lp > 3 that a second launch
+ * decodes) lives in a device array of the library's own, about 58 MiB on every GPU the
+ * library has run this call on, kept until the process ends; the call itself makes no
+ * hipMalloc / hipFree.  Limits: at most 2^20 streams per call (more: LZMA_AMD_ERR_ARG);
+ * 4096 workgroups, so about half the throughput of the allocating call on large batches.
+ * Every call on a GPU uses that GPU's one array: calls that overlap in time on the same
+ * GPU (from several threads or streams) race and must be serialised by the caller. */
+int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_streams,
+                                      uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                                      int32_t *d_status, void *stream);
+
 /* Header fields of one stream (props.decodeProps, lzma_decoder.go:175-190, and
  * the size field :318-322), host-side helper for sizing decode outputs. */
 int lzma_amd_parse_header(const uint8_t *in, size_t n, uint32_t *lc, uint32_t *lp, uint32_t *pb,

@@ -24,6 +24,7 @@ EXPORTS = [
     "lzma_amd_bt4_matches_dev", "lzma_amd_encode_chunks", "lzma_amd_encode_chunks_dev",
     "lzma_amd_decode_batch", "lzma_amd_decode_batch_dev", "lzma_amd_parse_header",
     "lzma_amd_last_timing", "lzma_amd_last_coder_launches", "lzma_amd_release_workspace",
+    "lzma_amd_decode_batch_dev_noalloc",
 ]
 
 
@@ -66,6 +67,7 @@ def lib():
     L.lzma_amd_encode_chunks_dev.argtypes = [vp, vp, sz, sz, C.POINTER(Params), vp, vp, vp, vp, vp]
     L.lzma_amd_decode_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.lzma_amd_decode_batch_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
+    L.lzma_amd_decode_batch_dev_noalloc.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
     L.lzma_amd_parse_header.argtypes = [vp, sz] + [C.POINTER(C.c_uint32)] * 4 + [C.POINTER(C.c_int64)]
     L.lzma_amd_last_timing.argtypes = [C.POINTER(C.c_float)] * 3
     L.lzma_amd_last_coder_launches.restype = C.c_int

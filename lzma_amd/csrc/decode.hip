@@ -18,6 +18,7 @@
 // Roofline class: HBM-bound in principle (reads C compressed bytes, writes N raw
 // bytes per stream), instruction-issue-bound in practice.
 #include <algorithm>
+#include <mutex>
 
 #include "host_util.hpp"
 #include "lzma_dec_core.hpp"
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decod
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint64_t n_streams,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint32_t *big_count,
-    uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride) {
+    uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride, uint32_t lit_small_log) {
     __shared__ __align__(16) lz::prob_t s_probs[lz::kNumBaseProbs];
     const uint32_t lane = threadIdx.x;
     lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_scratch_stride;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decod
             continue;
         }
         const uint32_t lit_n = 0x300u << (h.lc + h.lp);
-        if (!BIG && h.lc + h.lp > kLitSmallLog) {
+        if (!BIG && h.lc + h.lp > lit_small_log) {
             if (lane == 0) {
                 uint32_t k = atomicAdd(big_count, 1u);
                 big_list[k] = (uint32_t)s;
@@ -117,7 +118,7 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     tm.start(st);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
                        (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big.as<uint32_t>(),
-                       big.as<uint32_t>() + 1, lit_small.as<lz::prob_t>(), kLitSmall);
+                       big.as<uint32_t>() + 1, lit_small.as<lz::prob_t>(), kLitSmall, kLitSmallLog);
     LZ_HIP(hipGetLastError());
     uint32_t n_big = 0;
     LZ_HIP(hipMemcpyAsync(&n_big, big.p, sizeof n_big, hipMemcpyDeviceToHost, st));
@@ -128,13 +129,85 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
         LZ_HIP(scratch.alloc((size_t)wgs * kLitBig * sizeof(lz::prob_t)));
         hipLaunchKernelGGL(decode_kernel<true>, dim3(wgs), dim3(64), 0, st, d_in, d_in_off,
                            (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
-                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(), kLitBig);
+                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(), kLitBig, kLitSmallLog);
         LZ_HIP(hipGetLastError());
     }
     tm.stop();
     LZ_HIP(hipStreamSynchronize(st));
     lzh::tls().ms_total = lzh::tls().ms_coder = tm.ms();
     lzh::tls().coder_launches = n_big > 0 ? 2 : 1;
+    return LZMA_AMD_OK;
+}
+
+// ---------------------------------------------------------------- no allocation
+// The same decode for callers that cannot allocate (code under HIP graph capture, tight
+// serving loops): everything the kernels need beyond the caller's buffers -- the literal
+// models of each workgroup and the list of streams deferred to the second launch -- lives
+// in a file-scope device array, so the call makes no hipMalloc/hipFree.  The array is
+// smaller than what lzma_amd_decode_batch_dev allocates, so fewer workgroups run at once.
+namespace {
+constexpr uint32_t kNaLitLog = 3;                                // lc+lp handled by the first launch
+constexpr uint64_t kNaLitModels = 0x300ull << kNaLitLog;         // models per workgroup area
+constexpr uint32_t kNaGrid = 4096;                               // workgroups of the first launch
+constexpr uint64_t kNaMaxStreams = 1ull << 20;                   // streams per call
+constexpr uint64_t kNaSmallBytes = kNaGrid * kNaLitModels * sizeof(lz::prob_t);  // 48 MiB
+constexpr uint64_t kNaBigBytes = kLitBig * sizeof(lz::prob_t);   // one full-size area, 6 MiB
+constexpr uint64_t kNaListBytes = (kNaMaxStreams + 64) * sizeof(uint32_t);
+constexpr uint64_t kNaScratchBytes = kNaSmallBytes + kNaBigBytes + kNaListBytes;
+static __device__ __align__(256) uint8_t scratch[kNaScratchBytes];
+
+constexpr int kNaMaxDevices = 64;
+uint8_t *g_na_ptr[kNaMaxDevices] = {};  // the array's address on each device, looked up once
+std::mutex g_na_mutex;
+
+// The array's device address on the current device (each device has its own copy at its own
+// address); the name `scratch` itself is only a host-side handle.
+int na_scratch(uint8_t **out) {
+    int dev = 0;
+    LZ_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kNaMaxDevices) return lzh::fail(LZMA_AMD_ERR_UNSUPPORTED, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_na_mutex);
+    if (!g_na_ptr[dev]) {
+        void *p = nullptr;
+        LZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_na_ptr[dev] = (uint8_t *)p;
+    }
+    *out = g_na_ptr[dev];
+    return LZMA_AMD_OK;
+}
+}  // namespace
+
+extern "C" int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off,
+                                                 size_t n_streams, uint8_t *d_out,
+                                                 const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                                                 int32_t *d_status, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_streams == 0) return LZMA_AMD_OK;
+    if (!d_in || !d_in_off || !d_out || !d_out_off || !d_out_sizes || !d_status)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
+    if (n_streams > kNaMaxStreams)
+        return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch_dev_noalloc: %zu streams, at most %llu per call", n_streams,
+                         (unsigned long long)kNaMaxStreams);
+    uint8_t *base = nullptr;
+    int rc = na_scratch(&base);
+    if (rc) return rc;
+    lz::prob_t *lit_small = (lz::prob_t *)base;
+    lz::prob_t *lit_big = (lz::prob_t *)(base + kNaSmallBytes);
+    uint32_t *big = (uint32_t *)(base + kNaSmallBytes + kNaBigBytes);  // [0] = count, [64..] = deferred streams
+    // the array keeps the previous call's contents: the count must start at zero (the literal
+    // areas are initialised by each workgroup, the list is only read up to the count)
+    LZ_HIP(hipMemsetAsync(big, 0, 256, st));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, kNaGrid);
+    hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
+                       (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small,
+                       kNaLitModels, kNaLitLog);
+    LZ_HIP(hipGetLastError());
+    // the second launch reads the count on the device: one workgroup with the full-size area
+    // takes the deferred streams in turn (none: it returns at once)
+    hipLaunchKernelGGL(decode_kernel<true>, dim3(1), dim3(64), 0, st, d_in, d_in_off, (uint64_t)n_streams,
+                       d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_big, kLitBig, kNaLitLog);
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipStreamSynchronize(st));
     return LZMA_AMD_OK;
 }
 
