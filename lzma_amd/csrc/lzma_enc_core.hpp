@@ -77,6 +77,57 @@ LZ_HD uint32_t enc_small_words(uint32_t fb) {
 #define LZ_PAR_END }
 #endif
 
+// Values that differ from lane to lane and are read across lanes: on the GPU a vector
+// register, read with readlane (one lane's value for all, LZ_FROM_LANE) or reduced over the
+// wave (LZ_WAVE_MAX, LZ_WAVE_COUNT; all 64 lanes must execute these); on the host an array with one element per
+// lane.  LZ_LV(name, L) is lane L's element inside a parallel section.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define LZ_LANEVAR(name) uint32_t name = 0
+#define LZ_LV(name, L) name
+#define LZ_FROM_LANE(name, k) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(k)))
+template <int K>
+LZ_D uint32_t lz_row_shr(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xF, 0xF, false);
+}
+LZ_D uint32_t lz_wave_max(uint32_t v) {
+    // each shifted value is taken once, by all lanes, before it is compared: a cross-lane move
+    // inside a conditional would run with some lanes switched off and read nothing from them
+    uint32_t t = lz_row_shr<1>(v);
+    v = v > t ? v : t;
+    t = lz_row_shr<2>(v);
+    v = v > t ? v : t;
+    t = lz_row_shr<4>(v);
+    v = v > t ? v : t;
+    t = lz_row_shr<8>(v);
+    v = v > t ? v : t;  // lane 15 of every row: the row's maximum
+    const uint32_t a = LZ_FROM_LANE(v, 15), b = LZ_FROM_LANE(v, 31), c = LZ_FROM_LANE(v, 47), d = LZ_FROM_LANE(v, 63);
+    const uint32_t x = a > b ? a : b, y = c > d ? c : d;
+    return x > y ? x : y;
+}
+#define LZ_WAVE_MAX(name) lz_wave_max(name)
+#define LZ_WAVE_COUNT(name) ((uint32_t)__builtin_popcountll(__ballot((name) != 0)))
+#define LZ_LANES_BEGIN(L) { const uint32_t L = lane_id;
+#define LZ_LANES_END }
+#else
+#define LZ_LANEVAR(name) uint32_t name[kLanes] = {}
+#define LZ_LV(name, L) name[L]
+#define LZ_FROM_LANE(name, k) name[k]
+inline uint32_t lz_wave_max_host(const uint32_t *v) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < kLanes; i++) m = v[i] > m ? v[i] : m;
+    return m;
+}
+#define LZ_WAVE_MAX(name) lz_wave_max_host(name)
+inline uint32_t lz_wave_count_host(const uint32_t *v) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < kLanes; i++) m += v[i] != 0;
+    return m;
+}
+#define LZ_WAVE_COUNT(name) lz_wave_count_host(name)
+#define LZ_LANES_BEGIN(L) for (uint32_t L = 0; L < kLanes; L++) {
+#define LZ_LANES_END }
+#endif
+
 // Section timing for diagnostic builds (-DLZ_PROFILE): LZ_LAP(i) charges the cycles since
 // the previous lap to section i.  Compiled out otherwise.
 #if defined(LZ_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -183,6 +234,37 @@ struct Encoder {
 #if defined(LZ_PROFILE)
     uint64_t prof[12], prof_last;
 #endif
+
+    // ---- prices that depend only on (state, posState)
+    struct StatePrices {
+        uint32_t im0, rep_match, nmp, rep_len1, prp[4];
+    };
+    LZ_HD StatePrices sp_direct(uint32_t st, uint32_t ps) const {  // lzma_encoder.go:566-597, per lane
+        const uint32_t im_v = probs[P_IS_MATCH + ((st << kPosStatesBitsMax) + ps)], ir_v = probs[P_IS_REP + st];
+        const uint32_t g0_v = probs[P_IS_REP_G0 + st], g1_v = probs[P_IS_REP_G1 + st];
+        const uint32_t g2_v = probs[P_IS_REP_G2 + st], rl_v = probs[P_IS_REP0_LONG + ((st << kPosStatesBitsMax) + ps)];
+        const uint32_t im0 = price0(im_v), im1 = price1(im_v), ir0 = price0(ir_v), ir1 = price1(ir_v);
+        const uint32_t g00 = price0(g0_v), g01 = price1(g0_v), g10 = price0(g1_v), g11 = price1(g1_v);
+        const uint32_t g20 = price0(g2_v), g21 = price1(g2_v), rl0 = price0(rl_v), rl1 = price1(rl_v);
+        StatePrices r;
+        r.im0 = im0;
+        r.rep_match = im1 + ir1;
+        r.nmp = im1 + ir0;
+        r.rep_len1 = g00 + rl0;
+        r.prp[0] = r.rep_match + g00 + rl1;
+        r.prp[1] = r.rep_match + g01 + g10;
+        r.prp[2] = r.rep_match + g01 + g11 + g20;
+        r.prp[3] = r.rep_match + g01 + g11 + g21;
+        return r;
+    }
+    // the same for a wave-uniform (state, posState), in scalar registers
+    LZ_HD StatePrices sp_get(uint32_t st, uint32_t ps) const {
+        const StatePrices v = sp_direct(st, ps);
+        StatePrices r;
+        r.im0 = U(v.im0), r.rep_match = U(v.rep_match), r.nmp = U(v.nmp), r.rep_len1 = U(v.rep_len1);
+        r.prp[0] = U(v.prp[0]), r.prp[1] = U(v.prp[1]), r.prp[2] = U(v.prp[2]), r.prp[3] = U(v.prp[3]);
+        return r;
+    }
 
     // ---- range encoder, range_coder.go:131-138 ----
     uint64_t low, out_n;
@@ -687,6 +769,36 @@ struct Encoder {
         return x > y ? x : y;
     }
 
+    // One lane's task in a round of the parse (see get_optimum): which two byte streams it
+    // compares (a at a_off, b `dist + 1` before it) and how far.
+    struct RoundTask {
+        bool is_rep, is_lit, is_pair, active;
+        uint32_t a_off, dist, lim1, lim2, lt_pair;
+    };
+    LZ_HD RoundTask round_task(uint32_t L, uint32_t jbase, bool do_rest, uint32_t npairs, uint32_t r0, uint32_t r1,
+                               uint32_t r2, uint32_t r3, uint32_t av, uint32_t avail_full) const {
+        const uint32_t fb = ep.fb;
+        const bool first = jbase == 0;
+        const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
+        RoundTask t;
+        t.is_rep = first && L < kNumReps, t.is_lit = first && L == 4;
+        t.is_pair = do_rest && L >= 8 && j < npairs;
+        t.a_off = mfpos - 1, t.dist = 0, t.lim1 = 0, t.lim2 = 0, t.lt_pair = 0;
+        if (t.is_rep) {
+            t.dist = L == 0 ? r0 : (L == 1 ? r1 : (L == 2 ? r2 : r3));
+            if (do_rest) t.lim1 = av;
+        } else if (t.is_lit) {
+            t.dist = r0;
+            if (do_rest) t.lim2 = avail_full - 1 < fb ? avail_full - 1 : fb;
+        } else if (t.is_pair) {
+            t.lt_pair = mdist[2 * j], t.dist = mdist[2 * j + 1];
+            t.a_off += t.lt_pair;
+            if (t.lt_pair < avail_full) t.lim2 = avail_full - 1 - t.lt_pair < fb ? avail_full - 1 - t.lt_pair : fb;
+        }
+        t.active = t.is_rep || t.is_lit || (t.is_pair && t.lim2 != 0);
+        return t;
+    }
+
     LZ_HD uint32_t get_optimum(uint32_t position) {  // :359-797
         const uint32_t fb = ep.fb;
         if (opt_end != opt_cur) {
@@ -711,18 +823,24 @@ struct Encoder {
             back_res = 0xFFFFFFFFu;
             return 1;
         }
-        // rep lengths and the two bytes the literal needs, in parallel
+        // rep lengths and the two bytes the literal needs, in parallel: lanes 0-3 and lane 4
+        // hand their results over in x0 / x1
+        LZ_LANEVAR(x0);
+        LZ_LANEVAR(x1);
+        LZ_LANEVAR(x2);
+        LZ_LANEVAR(x3);
         LZ_PAR_BEGIN(L)
         if (L < kNumReps) {
-            rep_lens[L] = match_len(-1, rep_dist[L], kMatchMax);
+            LZ_LV(x0, L) = match_len(-1, rep_dist[L], kMatchMax);
         } else if (L == 4) {
-            xch[0] = index_byte(-1);
-            xch[1] = index_byte(0 - (int32_t)rep_dist[0] - 1 - 1);
+            LZ_LV(x0, L) = index_byte(-1);
+            LZ_LV(x1, L) = index_byte(0 - (int32_t)rep_dist[0] - 1 - 1);
         }
         LZ_PAR_END
         uint32_t r0 = U(rep_dist[0]), r1 = U(rep_dist[1]), r2 = U(rep_dist[2]), r3 = U(rep_dist[3]);  // z.reps
         ApplyIn A;
-        for (uint32_t i = 0; i < kNumReps; i++) A.rl[i] = U(rep_lens[i]);
+        A.rl[0] = LZ_FROM_LANE(x0, 0), A.rl[1] = LZ_FROM_LANE(x0, 1);
+        A.rl[2] = LZ_FROM_LANE(x0, 2), A.rl[3] = LZ_FROM_LANE(x0, 3);
         // (no indexing by a variable: that would put the whole struct in scratch memory)
         uint32_t rep_max = 0, rep_max_len = A.rl[0];
 #pragma unroll
@@ -738,32 +856,21 @@ struct Encoder {
             move_pos(len_main - 1);
             return len_main;
         }
-        const uint32_t cur_byte0 = U(xch[0]), match_byte0 = U(xch[1]);
+        const uint32_t cur_byte0 = LZ_FROM_LANE(x0, 4), match_byte0 = LZ_FROM_LANE(x1, 4);
         if (len_main < 2 && cur_byte0 != match_byte0 && rep_max_len < 2) {
             back_res = 0xFFFFFFFFu;
             return 1;
         }
         uint32_t ps = position & pos_state_mask;
         uint32_t rep_len1;
-        uint32_t match_price, rep_match_price, nmp;
+        uint32_t rep_match_price, nmp;
         {
-            const uint32_t im_v = probs[P_IS_MATCH + LZ_IDX(state, ps)], ir_v = probs[P_IS_REP + state];
-            const uint32_t g0_v = probs[P_IS_REP_G0 + state], g1_v = probs[P_IS_REP_G1 + state];
-            const uint32_t g2_v = probs[P_IS_REP_G2 + state], rl_v = probs[P_IS_REP0_LONG + LZ_IDX(state, ps)];
-            const uint32_t im0_v = price0(im_v), im1_v = price1(im_v), ir0_v = price0(ir_v), ir1_v = price1(ir_v);
-            const uint32_t g00_v = price0(g0_v), g01_v = price1(g0_v), g10_v = price0(g1_v), g11_v = price1(g1_v);
-            const uint32_t g20_v = price0(g2_v), g21_v = price1(g2_v), rl0_v = price0(rl_v), rl1_v = price1(rl_v);
-            const uint32_t im0 = U(im0_v), im1 = U(im1_v), ir0 = U(ir0_v), ir1 = U(ir1_v);
-            const uint32_t g00 = U(g00_v), g01 = U(g01_v), g10 = U(g10_v), g11 = U(g11_v);
-            const uint32_t g20 = U(g20_v), g21 = U(g21_v), rl0 = U(rl0_v), rl1 = U(rl1_v);
-            match_price = im1;
-            rep_match_price = match_price + ir1;
-            nmp = match_price + ir0;
-            A.prp[0] = rep_match_price + g00 + rl1;
-            A.prp[1] = rep_match_price + g01 + g10;
-            A.prp[2] = rep_match_price + g01 + g11 + g20;
-            A.prp[3] = rep_match_price + g01 + g11 + g21;
-            rep_len1 = g00 + rl0;
+            const StatePrices sp0 = sp_get(state, ps);
+            const uint32_t im0 = sp0.im0;
+            rep_match_price = sp0.rep_match;
+            nmp = sp0.nmp;
+            A.prp[0] = sp0.prp[0], A.prp[1] = sp0.prp[1], A.prp[2] = sp0.prp[2], A.prp[3] = sp0.prp[3];
+            rep_len1 = sp0.rep_len1;
             uint32_t price1_ = im0 + U(lit_price(lit_sub(position, prev_byte), !st_is_char(state),
                                                  match_byte0, cur_byte0));
             uint32_t back1 = 0xFFFFFFFFu;
@@ -821,6 +928,19 @@ struct Encoder {
                 return backward(cur);
             }
             position++;
+            // what is left of the chunk and of the optimum table bounds every length from here (:627, :724-731)
+            uint32_t avail_full = kNumOpts - 1 - cur;
+            if (avail() + 1 < avail_full) avail_full = avail() + 1;
+            const uint32_t av = avail_full < fb ? avail_full : fb;
+            const bool do_rest = avail_full >= 2;
+            uint32_t npairs = dpairs >> 1;
+            if (do_rest && new_len > av) {  // :724-731
+                new_len = av;
+                uint32_t j = 0;
+                while (new_len > U(mdist[2 * j])) j++;
+                if (one()) mdist[2 * j] = new_len;
+                npairs = j + 1;
+            }
             // ---- state and reps of the path that reaches cur (:525-597).  The entry E the
             // path comes from always holds the reps to permute (for a literal or short rep it
             // is cur-1, whose reps are the current ones).
@@ -885,36 +1005,13 @@ struct Encoder {
             // price table in one batch
             uint32_t p_im0;
             {
-                const uint32_t im_v = probs[P_IS_MATCH + LZ_IDX(st, ps)], ir_v = probs[P_IS_REP + st];
-                const uint32_t g0_v = probs[P_IS_REP_G0 + st], g1_v = probs[P_IS_REP_G1 + st];
-                const uint32_t g2_v = probs[P_IS_REP_G2 + st], rl_v = probs[P_IS_REP0_LONG + LZ_IDX(st, ps)];
-                const uint32_t im0_v = price0(im_v), im1_v = price1(im_v), ir0_v = price0(ir_v), ir1_v = price1(ir_v);
-                const uint32_t g00_v = price0(g0_v), g01_v = price1(g0_v), g10_v = price0(g1_v), g11_v = price1(g1_v);
-                const uint32_t g20_v = price0(g2_v), g21_v = price1(g2_v), rl0_v = price0(rl_v), rl1_v = price1(rl_v);
-                const uint32_t im0 = U(im0_v), im1 = U(im1_v), ir0 = U(ir0_v), ir1 = U(ir1_v);
-                const uint32_t g00 = U(g00_v), g01 = U(g01_v), g10 = U(g10_v), g11 = U(g11_v);
-                const uint32_t g20 = U(g20_v), g21 = U(g21_v), rl0 = U(rl0_v), rl1 = U(rl1_v);
-                p_im0 = im0;
-                match_price = cur_price + im1;
-                rep_match_price = match_price + ir1;
-                nmp = match_price + ir0;
-                A.prp[0] = rep_match_price + g00 + rl1;
-                A.prp[1] = rep_match_price + g01 + g10;
-                A.prp[2] = rep_match_price + g01 + g11 + g20;
-                A.prp[3] = rep_match_price + g01 + g11 + g21;
-                rep_len1 = g00 + rl0;
-            }
-            uint32_t avail_full = kNumOpts - 1 - cur;
-            if (avail() + 1 < avail_full) avail_full = avail() + 1;
-            const uint32_t av = avail_full < fb ? avail_full : fb;
-            const bool do_rest = avail_full >= 2;
-            uint32_t npairs = dpairs >> 1;
-            if (do_rest && new_len > av) {  // :724-731
-                new_len = av;
-                uint32_t j = 0;
-                while (new_len > U(mdist[2 * j])) j++;
-                if (one()) mdist[2 * j] = new_len;
-                npairs = j + 1;
+                const StatePrices spc = sp_get(st, ps);
+                p_im0 = spc.im0;
+                rep_match_price = cur_price + spc.rep_match;
+                nmp = cur_price + spc.nmp;
+                A.prp[0] = cur_price + spc.prp[0], A.prp[1] = cur_price + spc.prp[1];
+                A.prp[2] = cur_price + spc.prp[2], A.prp[3] = cur_price + spc.prp[3];
+                rep_len1 = spc.rep_len1;
             }
             LZ_LAP(1)
             // ---- the round: every lane runs the same code on its own task.
@@ -928,22 +1025,11 @@ struct Encoder {
             for (uint32_t jbase = 0; jbase == 0 || jbase < npairs; jbase += kLanes - 8) {
                 const bool first = jbase == 0;
                 const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
-                const bool is_rep = first && L < kNumReps, is_lit = first && L == 4;
-                const bool is_pair = do_rest && L >= 8 && j < npairs;
-                uint32_t a_off = mfpos - 1, dist = 0, lim1 = 0, lim2 = 0, lt_pair = 0, rprp = 0;
-                if (is_rep) {
-                    dist = L == 0 ? r0 : (L == 1 ? r1 : (L == 2 ? r2 : r3));
-                    rprp = L == 0 ? A.prp[0] : (L == 1 ? A.prp[1] : (L == 2 ? A.prp[2] : A.prp[3]));
-                    if (do_rest) lim1 = av;
-                } else if (is_lit) {
-                    dist = r0;
-                    if (do_rest) lim2 = avail_full - 1 < fb ? avail_full - 1 : fb;
-                } else if (is_pair) {
-                    lt_pair = mdist[2 * j], dist = mdist[2 * j + 1];
-                    a_off += lt_pair;
-                    if (lt_pair < avail_full) lim2 = avail_full - 1 - lt_pair < fb ? avail_full - 1 - lt_pair : fb;
-                }
-                const bool active = is_rep || is_lit || (is_pair && lim2 != 0);
+                const RoundTask t = round_task(L, jbase, do_rest, npairs, r0, r1, r2, r3, av, avail_full);
+                const bool is_rep = t.is_rep, is_lit = t.is_lit, is_pair = t.is_pair, active = t.active;
+                const uint32_t a_off = t.a_off, dist = t.dist, lim1 = t.lim1, lt_pair = t.lt_pair;
+                uint32_t lim2 = t.lim2, rprp = 0;
+                if (is_rep) rprp = L == 0 ? A.prp[0] : (L == 1 ? A.prp[1] : (L == 2 ? A.prp[2] : A.prp[3]));
                 uint32_t s1 = 0, s2 = 0, cur_b = 0, match_b = 0, prev_b = 0;
                 bool tail = false;
                 if (active) {
@@ -952,8 +1038,8 @@ struct Encoder {
                     const uint32_t left = n - a_off;  // bytes of the chunk from a on (>= 1)
                     if (a_off + 16 <= readable) {
                         const uint64_t a0 = enc_load8(a), b0 = enc_load8(b), a1 = enc_load8(a + 8), b1 = enc_load8(b + 8);
-                        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
                         const uint32_t pv = a[-1];
+                        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
                         // equal bytes from offset `from` inside the 16 fetched (16 - from if all equal)
                         auto run16 = [&](uint32_t from) -> uint32_t {
                             if (from >= 16) return 0;
@@ -1004,14 +1090,15 @@ struct Encoder {
                         }
                     }
                 }
-                uint32_t tgt = 0;
+                const uint32_t lt_any = is_rep ? s1 : lt_pair;  // 0 for the literal lane
+                uint32_t tgt = 0, la_p = 0;
                 if (tail && (is_lit || s2 >= 2)) {
-                    const uint32_t lt = is_rep ? s1 : lt_pair;  // 0 for the literal lane
+                    const uint32_t lt = lt_any;
                     const uint32_t pos_after = position + lt;
                     const bool mode = is_lit ? !st_is_char(st) : true;
                     const uint32_t litp = lit_price(lit_sub(pos_after, prev_b), mode, match_b, cur_b);
                     if (is_lit) {
-                        xch[0] = cur_b, xch[1] = match_b, xch[2] = litp, xch[3] = s2;
+                        LZ_LV(x0, L) = cur_b, LZ_LV(x1, L) = match_b, LZ_LV(x2, L) = litp, LZ_LV(x3, L) = s2;
                     } else {
                         const uint32_t s_after = is_rep ? st_rep(st) : st_match(st);
                         const uint32_t s2s = st_char(s_after);
@@ -1020,29 +1107,31 @@ struct Encoder {
                         const uint32_t m_a = probs[P_IS_MATCH + LZ_IDX(s_after, psn)];
                         const uint32_t m_b = probs[P_IS_MATCH + LZ_IDX(s2s, psn2)], m_c = probs[P_IS_REP + s2s];
                         const uint32_t m_d = probs[P_IS_REP_G0 + s2s], m_e = probs[P_IS_REP0_LONG + LZ_IDX(s2s, psn2)];
+                        const uint32_t g_im0 = price0(m_a);
+                        const uint32_t g_tail = price1(m_b) + price1(m_c) + price0(m_d) + price1(m_e);
                         const uint32_t base = is_rep ? rprp + len_price(1, lt - kMatchMin, ps)
                                                      : nmp + pos_len_price(dist, lt, ps);
-                        const uint32_t p = base + price0(m_a) + litp + price1(m_b) + price1(m_c) +
-                                           len_price(1, s2 - kMatchMin, psn2) + price0(m_d) + price1(m_e);
+                        la_p = base + g_im0 + litp + g_tail + len_price(1, s2 - kMatchMin, psn2);
                         tgt = cur + lt + 1 + s2;
-                        la_price[is_rep ? 1 + L : 5 + j] = p;
                     }
                 }
+                // lanes 0-3 hand over (rep length, continuation target, its price) in x0..x2; the
+                // pair lanes of the first pass their pair's length and target in x0, x1 (for the
+                // end of the parse range below) besides the arrays the apply phase reads
                 if (is_rep) {
-                    rep_lens[L] = s1, la_tgt[1 + L] = tgt;
-                } else if (is_lit) {
-                    la_tgt[0] = 0;
-                } else if (do_rest && L >= 8 && j < npairs) {
+                    LZ_LV(x0, L) = s1, LZ_LV(x1, L) = tgt, LZ_LV(x2, L) = la_p;
+                } else if (!is_lit && do_rest && L >= 8 && j < npairs) {
                     la_tgt[5 + j] = tgt;
+                    la_price[5 + j] = la_p;
+                    if (first) LZ_LV(x0, L) = lt_pair, LZ_LV(x1, L) = tgt;
                 }
             }
             LZ_PAR_END
 
             LZ_LAP(2)
             // ---- literal and short rep into entry cur+1 (:598-624)
-            const uint32_t x0_v = xch[0], x1_v = xch[1], x2_v = xch[2], x3_v = xch[3];
-            const uint32_t cur_byte = U(x0_v), match_byte = U(x1_v), lit_l2 = U(x3_v);
-            const uint32_t cur_and1 = cur_price + p_im0 + U(x2_v);
+            const uint32_t cur_byte = LZ_FROM_LANE(x0, 4), match_byte = LZ_FROM_LANE(x1, 4), lit_l2 = LZ_FROM_LANE(x3, 4);
+            const uint32_t cur_and1 = cur_price + p_im0 + LZ_FROM_LANE(x2, 4);
             uint32_t nx_price = nxr.price;
             bool next_is_char = false, nx_changed = false;
             uint32_t nx_back = 0, nx_pp = 0;
@@ -1076,22 +1165,21 @@ struct Encoder {
                 if (l2 >= 2) {
                     const uint32_t s2 = st_char(st);
                     const uint32_t psn = (position + 1) & pos_state_mask;
-                    const uint32_t m_a = probs[P_IS_MATCH + LZ_IDX(s2, psn)], m_b = probs[P_IS_REP + s2];
-                    const uint32_t m_c = probs[P_IS_REP_G0 + s2], m_d = probs[P_IS_REP0_LONG + LZ_IDX(s2, psn)];
-                    const uint32_t tail_v = price1(m_a) + price1(m_b) + len_price(1, l2 - kMatchMin, psn) +
-                                            price0(m_c) + price1(m_d);
+                    // "match, rep, rep0 of more than one byte" after the literal: the rep0 price of
+                    // (state after the literal, its posState) plus the length
+                    const uint32_t lenp_v = len_price(1, l2 - kMatchMin, psn);
+                    const uint32_t tail = sp_get(s2, psn).prp[0] + U(lenp_v);
                     A.lt[0] = cur + 1 + l2;
-                    A.lp[0] = cur_and1 + U(tail_v);
+                    A.lp[0] = cur_and1 + tail;
                     if (cur + 1 + l2 > new_end) new_end = cur + 1 + l2;
                 }
             }
-            {
-                uint32_t v_rl[4], v_lt[4], v_lp[4];
-                for (uint32_t ri = 0; ri < kNumReps; ri++)
-                    v_rl[ri] = rep_lens[ri], v_lt[ri] = la_tgt[1 + ri], v_lp[ri] = la_price[1 + ri];
-                for (uint32_t ri = 0; ri < kNumReps; ri++)
-                    A.rl[ri] = U(v_rl[ri]), A.lt[1 + ri] = U(v_lt[ri]), A.lp[1 + ri] = U(v_lp[ri]);
-            }
+            A.rl[0] = LZ_FROM_LANE(x0, 0), A.rl[1] = LZ_FROM_LANE(x0, 1);
+            A.rl[2] = LZ_FROM_LANE(x0, 2), A.rl[3] = LZ_FROM_LANE(x0, 3);
+            A.lt[1] = LZ_FROM_LANE(x1, 0), A.lt[2] = LZ_FROM_LANE(x1, 1);
+            A.lt[3] = LZ_FROM_LANE(x1, 2), A.lt[4] = LZ_FROM_LANE(x1, 3);
+            A.lp[1] = LZ_FROM_LANE(x2, 0), A.lp[2] = LZ_FROM_LANE(x2, 1);
+            A.lp[3] = LZ_FROM_LANE(x2, 2), A.lp[4] = LZ_FROM_LANE(x2, 3);
             LZ_LAP(10)
             const uint32_t start_len = A.rl[0] >= 2 ? A.rl[0] + 1 : 2;
             for (uint32_t ri = 0; ri < kNumReps; ri++) {
@@ -1103,11 +1191,26 @@ struct Encoder {
             if (new_len >= start_len) {
                 plain_len = new_len;
                 if (cur + new_len > new_end) new_end = cur + new_len;
-                first_la = 0;
-                while (U(mdist[2 * first_la]) < start_len) first_la++;
-                for (uint32_t j = first_la; j < npairs; j++) {
-                    const uint32_t tg = U(la_tgt[5 + j]);
-                    if (tg > new_end) new_end = tg;
+                // pairs shorter than start_len take no part (their lengths increase with the index);
+                // the first pass of the round left the pairs' lengths and targets in lanes 8..63
+                const uint32_t in_lanes = npairs < kLanes - 8 ? npairs : kLanes - 8;
+                LZ_LANEVAR(xs);
+                LZ_LANEVAR(xm);
+                LZ_LANES_BEGIN(L)
+                const bool mine = L >= 8 && L - 8 < in_lanes;
+                LZ_LV(xs, L) = mine && LZ_LV(x0, L) < start_len;
+                LZ_LV(xm, L) = (mine && LZ_LV(x0, L) >= start_len) ? LZ_LV(x1, L) : 0u;
+                LZ_LANES_END
+                first_la = LZ_WAVE_COUNT(xs);
+                const uint32_t tg_max = LZ_WAVE_MAX(xm);
+                if (tg_max > new_end) new_end = tg_max;
+                if (npairs > in_lanes) {  // lists longer than one pass of the round: the rest from memory
+                    if (first_la == in_lanes)
+                        while (U(mdist[2 * first_la]) < start_len) first_la++;
+                    for (uint32_t j = first_la > in_lanes ? first_la : in_lanes; j < npairs; j++) {
+                        const uint32_t tg = U(la_tgt[5 + j]);
+                        if (tg > new_end) new_end = tg;
+                    }
                 }
             }
             A.cur = cur, A.old_end = len_end, A.new_end = new_end, A.ps = ps, A.start_len = start_len;
