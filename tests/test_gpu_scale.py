@@ -115,3 +115,29 @@ print("retry ok")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "retry ok" in r.stdout, r.stdout + r.stderr
     assert r.stderr.count("arena grown") >= 2, r.stderr  # the finder call and the encoder call both grew it
+
+
+@pytest.mark.timeout(600)
+def test_c5_shape_full_chunk():
+    """configs[4]: one full 16 MiB chunk of the redundant log, dict 64 MiB, fb 273 (the match
+    lists take the two-word form: the dictionary is larger than the one-word form allows).
+    Too long for the oracle's encoder at the exhaustive cut value, so: the stream decodes back
+    through the oracle's decoder and liblzma; and on a 2 MiB chunk of the same data the bytes
+    equal the oracle's (exhaustive cut) and the size is within 1 % of the oracle's at the
+    reference's default cut value (16 + fb/2 = 152)."""
+    import lzma_amd
+    chunk = 1 << 24
+    data = synth.logtext(chunk + (2 << 20), block=chunk)
+    big, small = bytes(data[:chunk]), bytes(data[chunk:])
+    p = lzma_amd.make_params(26, 273)
+    st, outs = lzma_amd.encode_chunks([big, small], p)
+    assert (st == 0).all()
+    rc, back = O.decode(outs[0])
+    assert rc == 0 and back == big
+    assert pylzma.decompress(outs[0], format=pylzma.FORMAT_ALONE) == big
+    st2, dec = lzma_amd.decode_batch(outs)
+    assert (st2 == 0).all() and dec == [big, small]
+    want = O.encode(small, O.params(dict_log=26, fb=273, lc=3, lp=0, pb=2, cut=1 << 30, eos=False))
+    assert outs[1] == want
+    ref = O.encode(small, O.params(dict_log=26, fb=273, lc=3, lp=0, pb=2, cut=0, eos=False))
+    assert len(outs[1]) <= 1.01 * len(ref), (len(outs[1]), len(ref))

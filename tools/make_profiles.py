@@ -52,6 +52,45 @@ def bench_line(path):
     return lines[-1]
 
 
+def decode_summaries(run, prof, tag):
+    """Bench line, decode_kernel row of the kernel stats, and the counters per output byte."""
+    import ast
+    (prof / f"{tag}_bench_decode.json").write_text(bench_line(run / "bench_decode.txt") + "\n")
+    same = json.loads(bench_line(run / "ks_dec_log.txt"))
+    rows = [r for r in csv.DictReader(open(run / "dec_kernel_stats_raw.csv")) if "decode_kernel" in r["Name"]]
+    with open(prof / f"{tag}_decode_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload decode --no-cpu-baseline --no-verify  "
+                f"({same['config']['streams_total']} streams, 1 warmup + 2 timed steps; MI355X; durations in ns; the run's "
+                "other kernels belong to the encoder that prepares the streams and are left out)  -- the bench line of "
+                f"this same run: value {same['value']} MB/s, roofline.kernel_ms {same['roofline']['kernel_ms']}\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+        for r in rows:
+            f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
+                                                                       "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+    out_bytes = same["config"]["raw_bytes_this_rank"]
+    v = {}
+    for d in ("fetch", "write", "sq", "l2"):
+        for line in (run / "pmc_dec" / f"{d}.txt").read_text().splitlines():
+            v.update(ast.literal_eval(line[line.index("{"):]))
+    per = {k: round(x / out_bytes, 6 if k.endswith("SIZE") else 2) for k, x in v.items()}
+    per = {(k + "_KB" if k.endswith("SIZE") else k): x for k, x in per.items()}
+    per["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3)
+    per["hbm_bytes_per_output_byte_reported"] = round((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / out_bytes, 2)
+    res = {
+        "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --workload decode --steps 1 "
+                   "--warmup 0 --no-cpu-baseline --no-verify  (one run per counter group: FETCH_SIZE | WRITE_SIZE | "
+                   "SQ_* | TCC_HIT_sum TCC_MISS_sum)",
+        "workload": f"batched decode, {same['config']['streams_total']} streams of 4-64 KiB, {out_bytes:,} output bytes, MI355X",
+        "notes": ["values are per output byte, summed over all waves of decode_kernel<false>",
+                  "FETCH_SIZE / WRITE_SIZE in KB per output byte as rocprofv3 reports them (narrow accesses: "
+                  "uncalibrated on gfx950)",
+                  "SQ_* cycle counters in units of four cycles"],
+        "decode_kernel_per_output_byte": per}
+    (prof / f"{tag}_pmc_decode_{same['config']['streams_total'] // 1000}k_streams.json").write_text(
+        json.dumps(res, indent=1) + "\n")
+    print("decode", per)
+
+
 def main():
     run, tag, chunks = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
     prof = ROOT / "profiles"
@@ -85,6 +124,8 @@ def main():
             for r in rows:
                 f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
                                                                            "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+    if (run / "bench_decode.txt").exists():
+        decode_summaries(run, prof, tag)
     trace = sorted(csv.DictReader(open(run / "kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
     ours = [r for r in trace if kernel_class(r["Kernel_Name"]) != "other"]
     t0 = int(ours[0]["Start_Timestamp"])
