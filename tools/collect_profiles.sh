@@ -1,7 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box from the repository root: raw profiling outputs of the encode and
 # match-finder and decode benchmarks into gpurun_out/<tag>/ (condensed afterwards by tools/make_profiles.py).
-#   bash tools/collect_profiles.sh <tag>
+#   bash tools/collect_profiles.sh <tag> [round]
+# With a round name (r02) the summaries are made on the box as well, into gpurun_out/<tag>/profiles/, and the
+# large raw traces are dropped (gpurun_out/ carries at most 64 MiB back).
 # One rocprofv3 run per counter group; counters never together with a trace.
 set -e -o pipefail
 R=$(pwd)
@@ -26,7 +28,7 @@ for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
     n=${g%%:*}
     c=${g#*:}
     timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -o p -- \
-        python3 "$R/bench.py" --chunks 832 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmc_$n.log" 2>&1
+        python3 "$R/bench.py" --chunks 832 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-extra > "$OUT/pmc_$n.log" 2>&1
     cp "$(find "$OUT/pmc_$n" -name '*counter_collection.csv' | head -1)" "$OUT/pmc/$n.csv"
     rm -rf "$OUT/pmc_$n"
     echo "pmc pass $n done"
@@ -48,3 +50,7 @@ for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
     rm -rf "$OUT/pmcd_$n"
     echo "decode pmc pass $n done"
 done
+if [ -n "$2" ]; then
+    python3 "$R/tools/make_profiles.py" "$OUT" "$2" 832 "$OUT/profiles" > "$OUT/make_profiles.txt" 2>&1
+    rm -f "$OUT/kernel_trace.csv" "$OUT"/pmc/*.csv
+fi

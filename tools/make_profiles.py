@@ -1,6 +1,6 @@
 """Turns the raw outputs of tools/collect_profiles.sh into the encode and match-finder summaries kept under profiles/.
 
-    python tools/make_profiles.py gpurun_out/<run> r01 832
+    python tools/make_profiles.py gpurun_out/<run> r01 832 [output directory, default profiles/]
 
 The run directory holds what the collection script writes on the GPU box:
   bench_default.txt                       stdout of a plain bench.py run
@@ -91,10 +91,7 @@ def decode_summaries(run, prof, tag):
     print("decode", per)
 
 
-def main():
-    run, tag, chunks = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
-    prof = ROOT / "profiles"
-    prof.mkdir(exist_ok=True)
+def encode_stats(run, prof, tag):
     (prof / f"{tag}_bench_encode.json").write_text(bench_line(run / "bench_default.txt") + "\n")
     same = json.loads(bench_line(run / "ks_enc_log.txt"))
     rows = list(csv.DictReader(open(run / "kernel_stats_raw.csv")))
@@ -109,23 +106,42 @@ def main():
         for r in keep:
             f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
                                                                        "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+
+
+def mf_stats(run, prof, tag):
+    (prof / f"{tag}_bench_mf.json").write_text(bench_line(run / "bench_mf.txt") + "\n")
+    same = json.loads(bench_line(run / "ks_mf_log.txt"))
+    rows = [r for r in csv.DictReader(open(run / "mf_kernel_stats_raw.csv")) if kernel_class(r["Name"]) != "other"]
+    scan = [r for r in rows if "mf_scan" in r["Name"]][0]
+    with open(prof / f"{tag}_mf_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload mf --no-cpu-baseline --no-verify  "
+                "(256 MiB, dict 1 MiB, 1 warmup + 2 timed steps; MI355X; durations in ns; library kernel names "
+                "shortened to their rocprim entry point)  -- the bench line of this same run: "
+                f"value {same['value']} MB/s, roofline.kernel_ms {same['roofline']['kernel_ms']} "
+                f"(mf_scan_kernel average below: {float(scan['AverageNs']) / 1e6:.3f} ms)\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+        for r in rows:
+            f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
+                                                                       "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+
+
+def main():
+    run, tag, chunks = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+    prof = Path(sys.argv[4]) if len(sys.argv) > 4 else ROOT / "profiles"
+    prof.mkdir(exist_ok=True)
+    if (run / "bench_default.txt").exists():
+        encode_stats(run, prof, tag)
     if (run / "bench_mf.txt").exists():
-        (prof / f"{tag}_bench_mf.json").write_text(bench_line(run / "bench_mf.txt") + "\n")
-        same = json.loads(bench_line(run / "ks_mf_log.txt"))
-        rows = [r for r in csv.DictReader(open(run / "mf_kernel_stats_raw.csv")) if kernel_class(r["Name"]) != "other"]
-        scan = [r for r in rows if "mf_scan" in r["Name"]][0]
-        with open(prof / f"{tag}_mf_kernel_stats.csv", "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload mf --no-cpu-baseline --no-verify  "
-                    "(256 MiB, dict 1 MiB, 1 warmup + 2 timed steps; MI355X; durations in ns; library kernel names "
-                    "shortened to their rocprim entry point)  -- the bench line of this same run: "
-                    f"value {same['value']} MB/s, roofline.kernel_ms {same['roofline']['kernel_ms']} "
-                    f"(mf_scan_kernel average below: {float(scan['AverageNs']) / 1e6:.3f} ms)\n")
-            f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
-            for r in rows:
-                f.write(",".join([short_name(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs",
-                                                                           "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+        mf_stats(run, prof, tag)
     if (run / "bench_decode.txt").exists():
         decode_summaries(run, prof, tag)
+    if (run / "kernel_trace.csv").exists():
+        timeline(run, prof, tag)
+    if (run / "pmc" / "fetch.csv").exists():
+        counters(run, prof, tag, chunks)
+
+
+def timeline(run, prof, tag):
     trace = sorted(csv.DictReader(open(run / "kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
     ours = [r for r in trace if kernel_class(r["Kernel_Name"]) != "other"]
     t0 = int(ours[0]["Start_Timestamp"])
@@ -141,6 +157,9 @@ def main():
                 f.write(f"  scan {b:9.1f} {e:9.1f} {e - b:8.1f}\n")
             elif e - b > 30:
                 f.write(f"    k  {b:9.1f} {e:9.1f} {e - b:8.1f} {short_name(nm)}\n")
+
+
+def counters(run, prof, tag, chunks):
     out = {}
     for d in ("fetch", "write", "sq", "l2"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
