@@ -83,6 +83,7 @@ LZ_HD uint32_t enc_small_words(uint32_t fb) {
 // lane.  LZ_LV(name, L) is lane L's element inside a parallel section.
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define LZ_LANEVAR(name) uint32_t name = 0
+#define LZ_LANEARG(name) uint32_t name
 #define LZ_LV(name, L) name
 #define LZ_FROM_LANE(name, k) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(k)))
 template <int K>
@@ -110,6 +111,7 @@ LZ_D uint32_t lz_wave_max(uint32_t v) {
 #define LZ_LANES_END }
 #else
 #define LZ_LANEVAR(name) uint32_t name[kLanes] = {}
+#define LZ_LANEARG(name) const uint32_t *name
 #define LZ_LV(name, L) name[L]
 #define LZ_FROM_LANE(name, k) name[k]
 inline uint32_t lz_wave_max_host(const uint32_t *v) {
@@ -764,6 +766,86 @@ struct Encoder {
         }
         LZ_PAR_END
     }
+    // The same with the pairs' lengths, continuation targets and continuation prices taken
+    // from the lanes that computed them in the round (lane 8 + j: pair j; lists of up to
+    // kLanes - 8 pairs): each entry's lane counts the pairs shorter than its length and
+    // keeps the cheapest continuation landing on it while the pairs go by one at a time,
+    // with no trip through LDS per pair.  Candidates are compared in the order of apply().
+    LZ_HD void apply_lanes(const ApplyIn &A, LZ_LANEARG(pl_), LZ_LANEARG(tg_), LZ_LANEARG(pr_)) {
+        const uint32_t cur = A.cur, ps = A.ps;
+        const uint32_t rl_max = max4(A.rl[0], A.rl[1], A.rl[2], A.rl[3]);
+        for (uint32_t xb = cur + 2; xb <= A.new_end; xb += kLanes) {
+            LZ_LANEVAR(cnt);
+            LZ_LANEVAR(bp);
+            LZ_LANEVAR(bj);
+            LZ_LANES_BEGIN(L)
+            LZ_LV(cnt, L) = 0, LZ_LV(bp, L) = kInfPrice, LZ_LV(bj, L) = 0;
+            LZ_LANES_END
+            for (uint32_t j = 0; j < A.npairs; j++) {
+                const uint32_t pl = LZ_FROM_LANE(pl_, 8 + j), tg = LZ_FROM_LANE(tg_, 8 + j);
+                const uint32_t pr = LZ_FROM_LANE(pr_, 8 + j);
+                const bool la = j >= A.first_la && tg != 0;
+                LZ_LANES_BEGIN(L)
+                const uint32_t x = xb + L;
+                if (pl < x - cur) LZ_LV(cnt, L)++;
+                if (la && tg == x && pr < LZ_LV(bp, L)) LZ_LV(bp, L) = pr, LZ_LV(bj, L) = j;
+                LZ_LANES_END
+            }
+            LZ_PAR_BEGIN(L)
+            const uint32_t x = xb + L;
+            if (x <= A.new_end) {
+                const uint32_t len = x - cur;
+                uint32_t price = kInfPrice;
+                if (x <= A.old_end) price = oprice(x);
+                uint32_t rep_lp = 0, m_price = 0, m_dist = 0;
+                if (len <= rl_max) rep_lp = len_price(1, len - kMatchMin, ps);
+                const bool plain = A.new_len != 0 && len >= A.start_len && len <= A.new_len;
+                if (plain) {
+                    m_dist = mdist[2 * LZ_LV(cnt, L) + 1];
+                    m_price = A.nmp + pos_len_price(m_dist, len, ps);
+                }
+                bool changed = x > A.old_end;
+                uint32_t back = 0, ppw = 0, back2 = 0;
+                bool is_la = false;
+                if (A.lt[0] == x && A.lp[0] < price) {
+                    price = A.lp[0], back = 0, ppw = (cur + 1) | kPpPrev1, back2 = 0, is_la = true, changed = true;
+                }
+#pragma unroll
+                for (uint32_t ri = 0; ri < kNumReps; ri++) {
+                    const uint32_t lt = A.rl[ri];
+                    if (lt >= 2 && len <= lt) {
+                        const uint32_t p = A.prp[ri] + rep_lp;
+                        if (p < price) price = p, back = ri, ppw = cur, is_la = false, changed = true;
+                    }
+                    if (A.lt[1 + ri] == x && A.lp[1 + ri] < price) {
+                        price = A.lp[1 + ri], back = 0, back2 = ri;
+                        ppw = (cur + lt + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
+                        is_la = true, changed = true;
+                    }
+                }
+                if (LZ_LV(bp, L) < price) {
+                    const uint32_t j = LZ_LV(bj, L);
+                    price = LZ_LV(bp, L), back = 0, back2 = mdist[2 * j + 1] + kNumReps;
+                    ppw = (cur + mdist[2 * j] + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
+                    is_la = true, changed = true;
+                }
+                if (plain && m_price < price)
+                    price = m_price, back = m_dist + kNumReps, ppw = cur, is_la = false, changed = true;
+                if (changed) {
+                    if (price == kInfPrice) {
+                        set_price(x, price);
+                    } else if (is_la) {
+                        Rec r;
+                        r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
+                        srec(x, r);
+                    } else {
+                        set_pbp(x, price, back, ppw);
+                    }
+                }
+            }
+            LZ_PAR_END
+        }
+    }
     static LZ_HD uint32_t max4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         const uint32_t x = a > b ? a : b, y = c > d ? c : d;
         return x > y ? x : y;
@@ -1116,14 +1198,15 @@ struct Encoder {
                     }
                 }
                 // lanes 0-3 hand over (rep length, continuation target, its price) in x0..x2; the
-                // pair lanes of the first pass their pair's length and target in x0, x1 (for the
-                // end of the parse range below) besides the arrays the apply phase reads
+                // pair lanes of the first pass their pair's length, target and price in x0..x2
+                // (for the end of the parse range below and for the apply phase) besides the
+                // arrays a list longer than one pass is applied from
                 if (is_rep) {
                     LZ_LV(x0, L) = s1, LZ_LV(x1, L) = tgt, LZ_LV(x2, L) = la_p;
                 } else if (!is_lit && do_rest && L >= 8 && j < npairs) {
                     la_tgt[5 + j] = tgt;
                     la_price[5 + j] = la_p;
-                    if (first) LZ_LV(x0, L) = lt_pair, LZ_LV(x1, L) = tgt;
+                    if (first) LZ_LV(x0, L) = lt_pair, LZ_LV(x1, L) = tgt, LZ_LV(x2, L) = la_p;
                 }
             }
             LZ_PAR_END
@@ -1216,7 +1299,10 @@ struct Encoder {
             A.cur = cur, A.old_end = len_end, A.new_end = new_end, A.ps = ps, A.start_len = start_len;
             A.new_len = plain_len, A.nmp = nmp, A.npairs = npairs, A.first_la = first_la;
             LZ_LAP(3)
-            apply(A, true);
+            if (npairs <= kLanes - 8)
+                apply_lanes(A, x0, x1, x2);
+            else
+                apply(A, true);
             note_far(new_end);
             LZ_LAP(4)
             len_end = new_end;
