@@ -420,7 +420,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
 
     // all memory up front: nothing is allocated or freed while launches are in flight
     lzh::MfScratch &scratch = S.scratch;
-    if ((rc = scratch.reserve((uint32_t)max_bytes))) return rc;
+    if ((rc = scratch.reserve((uint32_t)max_bytes, ep.fb))) return rc;
     const int nslots = (int)std::min<size_t>(nbatches, in_flight + 1);
     Slot *slots = S.slots;
     for (int i = 0; i < nslots; i++) {

@@ -779,6 +779,7 @@ struct Encoder {
             LZ_LANEVAR(bp);
             LZ_LANEVAR(bj);
             LZ_LANES_BEGIN(L)
+            (void)L;
             LZ_LV(cnt, L) = 0, LZ_LV(bp, L) = kInfPrice, LZ_LV(bj, L) = 0;
             LZ_LANES_END
             for (uint32_t j = 0; j < A.npairs; j++) {
@@ -1108,7 +1109,7 @@ struct Encoder {
                 const bool first = jbase == 0;
                 const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
                 const RoundTask t = round_task(L, jbase, do_rest, npairs, r0, r1, r2, r3, av, avail_full);
-                const bool is_rep = t.is_rep, is_lit = t.is_lit, is_pair = t.is_pair, active = t.active;
+                const bool is_rep = t.is_rep, is_lit = t.is_lit, active = t.active;
                 const uint32_t a_off = t.a_off, dist = t.dist, lim1 = t.lim1, lt_pair = t.lt_pair;
                 uint32_t lim2 = t.lim2, rprp = 0;
                 if (is_rep) rprp = L == 0 ? A.prp[0] : (L == 1 ? A.prp[1] : (L == 2 ? A.prp[2] : A.prp[3]));

@@ -17,14 +17,15 @@
 //
 // To avoid scanning whole buckets (about 1400 candidates per position on text),
 // positions are also grouped by their exact first 6, 8 and 16 bytes (levels 1..3; the
-// hash-4 bucket is level 0).  All candidates sharing at least k bytes with P are in P's
+// hash-4 bucket is level 0), and for searches of 256 bytes and more (redundant data, where
+// thousands of positions share 16 bytes) by their first 32, 64 and 128 bytes (levels 4..6).  All candidates sharing at least k bytes with P are in P's
 // k-gram group; every member of a coarser group that is newer than the newest of them
 // (Qk) shares fewer than k.  So each level is scanned only down to the newest member of
 // the next level's group, from where the (much shorter) finer group takes over.
 //
 // All scans stream: the sorted tables carry, next to each position, the 8 bytes that
 // follow the bytes its group shares (bytes 0..7 in the bucket table, 6..13, 8..15 and
-// 16..23 in the others), so the lanes read consecutive 12-byte entries instead of
+// 16..23, ... in the others), so the lanes read consecutive 12-byte entries instead of
 // gathering from the window; only common prefixes of 24 bytes or more touch the window
 // itself.  A group's oldest entry carries a flag, so a scan knows where its group ends
 // without a second table.
@@ -34,9 +35,22 @@
 namespace lz {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kMfLevels = 4;
+constexpr uint32_t kMfLevels = 4;     // levels of an ordinary build
+constexpr uint32_t kMfMaxLevels = 7;  // with the deep levels, built for fb >= kMfDeepFb
+constexpr uint32_t kMfDeepFb = 256;
 // bytes the members of a level's group are known to share
-LZ_HD uint32_t mf_known(uint32_t level) { return level == 0 ? 0u : (level == 1 ? 6u : (level == 2 ? 8u : 16u)); }
+LZ_HD uint32_t mf_known(uint32_t level) {
+    return level == 0 ? 0u : (level == 1 ? 6u : (level == 2 ? 8u : 16u << (level - 3)));
+}
+// levels a build for `fb` over n positions has: a level needs searches that long, and the deep
+// ones a text several times their length (their order comes from shifting the previous level's)
+LZ_HD uint32_t mf_levels_for(uint32_t fb, uint32_t n) {
+    if (n < 32) return 1;
+    const uint32_t cap = fb >= kMfDeepFb ? kMfMaxLevels : kMfLevels;
+    uint32_t l = 1;
+    while (l < cap && fb >= mf_known(l) && (l < kMfLevels || n >= 4 * mf_known(l))) l++;
+    return l;
+}
 constexpr uint32_t kMfFirst = 0x80000000u;  // entry: it is the oldest of its group
 // A position's rank word says how many older members its group has, so that a search fetches
 // no more entries than can be candidates: tables of up to 2^30 entries keep a class in bits
@@ -64,18 +78,25 @@ struct MfEnt {
 // Per position: its rank word in each level's table (mf_rank_word)
 // and the previous position with the same hash-2 / hash-3 slot if it starts with the same byte
 // (kNone otherwise).
-struct __attribute__((aligned(16))) MfInfo {
-    uint32_t rank[kMfLevels];
-    uint32_t prev2, prev3, pad0, pad1;
+template <uint32_t NL>
+struct __attribute__((aligned(16))) MfInfoT {
+    uint32_t rank[NL];
+    uint32_t prev2, prev3;
+    uint32_t pad[NL == kMfLevels ? 2 : 3];
 };
+typedef MfInfoT<kMfLevels> MfInfo;        // 32 bytes
+typedef MfInfoT<kMfMaxLevels> MfInfoDeep;  // 48 bytes
+// words per record, and the words of prev2 / prev3 in it, for a build with `levels` levels
+LZ_HD uint32_t mf_info_words(uint32_t levels) { return levels > kMfLevels ? 12u : 8u; }
+LZ_HD uint32_t mf_info_prev(uint32_t levels) { return levels > kMfLevels ? kMfMaxLevels : kMfLevels; }
 
 struct MfTables {
     const uint8_t *data;  // all jobs' bytes, positions are offsets into it
     uint32_t n;           // bytes in data
-    const MfEnt *ent[kMfLevels];  // level l: (group, position) order, sig = bytes known(l) .. known(l)+7
-    const MfInfo *info;
+    const MfEnt *ent[kMfMaxLevels];  // level l: (group, position) order, sig = bytes known(l) .. known(l)+7
+    const void *info;     // MfInfo per position, MfInfoDeep if more than kMfLevels levels were built
     uint32_t dict, fb;
-    uint32_t levels;      // levels built (1 + those whose known bytes do not exceed fb)
+    uint32_t levels;      // levels built (mf_levels_for)
     uint32_t wide;        // more than 2^30 positions: rank words carry a flag instead of a class
     uint32_t packed;      // pairs are written as one word each (mf_pack) instead of two
 };
@@ -185,28 +206,38 @@ LZ_D uint64_t lane_get64(uint64_t v, int src) {
 
 // What a row knows about its position before any table entry is looked at: the record of
 // the position and 24 bytes of its text.
+template <uint32_t NL>
 struct MfPos {
-    MfInfo inf;
-    uint64_t p0, p8, p16;  // bytes 0..7, 8..15, 16..23 at P (zero beyond the buffer)
+    MfInfoT<NL> inf;
+    uint64_t p0, p8, p16;        // bytes 0..7, 8..15, 16..23 at P (zero beyond the buffer)
+    uint64_t pd[NL - kMfLevels + 1];  // deep levels: bytes 32..39, 64..71, 128..135 (one unused word otherwise)
 };
 // The 16 newest entries of every level's group (lane k of the row: the entry k + 1 places
 // below the position's own), requested in one batch.
+template <uint32_t NL>
 struct MfFront {
-    MfEnt e[kMfLevels];
+    MfEnt e[NL];
 };
 
-LZ_D void mf_load_pos(const MfTables &t, uint32_t P, bool act, MfPos &a) {
-    a.inf = MfInfo{};
+template <uint32_t NL>
+LZ_D void mf_load_pos(const MfTables &t, uint32_t P, bool act, MfPos<NL> &a) {
+    a.inf = MfInfoT<NL>{};
     a.p0 = a.p8 = a.p16 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < NL - kMfLevels + 1; i++) a.pd[i] = 0;
     if (act) {
-        a.inf = t.info[P];
+        a.inf = ((const MfInfoT<NL> *)t.info)[P];
         a.p0 = mf_load8(t.data, t.n, P), a.p8 = mf_load8(t.data, t.n, P + 8);
         a.p16 = mf_load8(t.data, t.n, P + 16);
+#pragma unroll
+        for (uint32_t l = kMfLevels; l < NL; l++)
+            if (l < t.levels) a.pd[l - kMfLevels] = mf_load8(t.data, t.n, P + mf_known(l));
     }
 }
-LZ_D void mf_load_front(const MfTables &t, const MfPos &a, bool act, uint32_t idx, MfFront &f) {
+template <uint32_t NL>
+LZ_D void mf_load_front(const MfTables &t, const MfPos<NL> &a, bool act, uint32_t idx, MfFront<NL> &f) {
 #pragma unroll
-    for (uint32_t l = 0; l < kMfLevels; l++) {
+    for (uint32_t l = 0; l < NL; l++) {
         f.e[l].pos = 0, f.e[l].sig_lo = 0, f.e[l].sig_hi = 0;
         const uint32_t w = a.inf.rank[l], r = mf_rank_of(w, t.wide != 0);
         // the rank words of levels that were not built are never looked at
@@ -323,7 +354,8 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t f
 // act == false take no part.  Returns the row's number of pairs; the pairs themselves are
 // written through `out` (a later pair with a smaller index overwrites: the reference drops
 // seed pairs that way).
-LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFront &f, uint32_t job_start,
+template <uint32_t NL>
+LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos<NL> &a, const MfFront<NL> &f, uint32_t job_start,
                        uint32_t job_end, bool act, const MfRowOut &out, uint32_t lane MF_PROF_ARG) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
     const uint32_t left = act ? job_end - P : 0;
@@ -339,10 +371,10 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFr
 
     // per level: the position's rank, whether it has an older member of its group at all, and
     // the newest such member
-    uint32_t top[kMfLevels], newest[kMfLevels], fetched[kMfLevels];
-    bool has[kMfLevels];
+    uint32_t top[NL], newest[NL], fetched[NL];
+    bool has[NL];
 #pragma unroll
-    for (uint32_t l = 0; l < kMfLevels; l++) {
+    for (uint32_t l = 0; l < NL; l++) {
         const uint32_t w = a.inf.rank[l], r = mf_rank_of(w, t.wide != 0);
         // a level is used if it was built and the position has that many bytes to compare
         const bool use = act && l < t.levels && (l == 0 || len_limit >= mf_known(l));
@@ -376,21 +408,24 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos &a, const MfFr
     MF_LAP(1)
     // each level down to the newest in-window member of the next level's group
     bool fin = false;
-    bool go[kMfLevels];
+    bool go[NL];
 #pragma unroll
-    for (uint32_t l = 0; l < kMfLevels; l++) go[l] = has[l] && (l == 0 || newest[l] >= W);
+    for (uint32_t l = 0; l < NL; l++) go[l] = has[l] && (l == 0 || newest[l] >= W);
 #pragma unroll
-    for (uint32_t l = 0; l < kMfLevels; l++) {
-        const uint32_t low = (l + 1 < kMfLevels && go[l + 1]) ? newest[l + 1] + 1 : W;
+    for (uint32_t l = 0; l < NL; l++) {
+        const uint32_t low = (l + 1 < NL && go[l + 1]) ? newest[l + 1] + 1 : W;
         uint64_t psig;
         if (l == 0) psig = a.p0;
         else if (l == 1) psig = (a.p0 >> 48) | (a.p8 << 16);
         else if (l == 2) psig = a.p8;
-        else psig = a.p16;
+        else if (l == 3) psig = a.p16;
+        else psig = a.pd[l < kMfLevels ? 0 : l - kMfLevels];
         // candidates of this level share fewer bytes than the next level's groups do
-        const uint32_t ceil = (l + 1 < kMfLevels && l + 1 < t.levels && len_limit >= mf_known(l + 1))
+        const uint32_t ceil = (l + 1 < NL && l + 1 < t.levels && len_limit >= mf_known(l + 1))
                                   ? mf_known(l + 1) - 1 : len_limit;
-        mf_level(t, t.ent[l], top[l], fetched[l], f.e[l], low, psig, mf_known(l), l + 1 == kMfLevels, P, len_limit, ceil,
+        // candidates can share more than the 8 bytes their entries carry from 16 bytes on, and at
+        // the last level built (a text too short for the finer levels)
+        mf_level(t, t.ent[l], top[l], fetched[l], f.e[l], low, psig, mf_known(l), l >= 3 || l + 1 >= t.levels, P, len_limit, ceil,
                  n, max_len, fin, go[l], out, lane MF_PROF_PASS);
     }
     return n;

@@ -8,11 +8,13 @@
 //      library primitive used -- giving each group's positions in ascending order.  The
 //      16-gram table needs no sort over 16 bytes: the positions in 8-gram order, each
 //      moved back by 8, are already ordered by their bytes 8..15, and one stable sort by
-//      the 8-gram group of bytes 0..7 (a 31-bit key) finishes the order;
+//      the 8-gram group of bytes 0..7 (a 31-bit key) finishes the order; the 32-, 64- and
+//      128-gram tables built for searches of 256 bytes and more come the same way, each
+//      from the one before it;
 //   3. table kernels: 12-byte entries (position, 8 bytes of its text; a flag on the oldest
 //      entry of each group) in sorted order for the hash-4 buckets and the 6-, 8- and
-//      16-gram groups, and per position its rank in each table and the previous position
-//      with the same hash-2 / hash-3 slot;
+//      16-gram (... 128-gram) groups, and per position its rank in each table and the
+//      previous position with the same hash-2 / hash-3 slot;
 //   4. the scan kernel (lzma_mf_core.hpp): four positions per wave, one per 16-lane row,
 //      16 candidates of every level per step, record breakers by a prefix maximum over the
 //      row.  The loads of a position (its record, then the newest entries of its groups)
@@ -91,50 +93,51 @@ __global__ __launch_bounds__(256) void mf_gid_kernel(const uint32_t *__restrict_
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) gid[ord[j]] = gstart[j];
 }
 
-// Input of the 16-gram sort.  ord8 holds the positions ordered by (bytes 0..7, position);
-// position p - 8 has p's bytes 0..7 as its bytes 8..15, so the sequence p - 8 is ordered by
-// (bytes 8..15, position), and a stable sort of it by the 8-gram group of bytes 0..7 orders it
-// by the first 16 bytes.  The eight positions at the end of the text, which have no position
-// eight ahead, take the places of p = 0..7 with keys of their own: no search looks at them
-// (a search at level 16 needs 16 bytes after its position and only meets older ones).
-__global__ __launch_bounds__(256) void mf_shift16_kernel(const uint32_t *__restrict__ ord8,
-                                                         const uint32_t *__restrict__ gid8, uint32_t n,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// Input of the sort that doubles the group length from k to 2k bytes (k = 8: the 16-gram
+// level from the 8-gram order, and so on).  ordk holds the positions ordered by (bytes 0..k-1,
+// position); position p - k has p's bytes 0..k-1 as its bytes k..2k-1, so the sequence p - k is
+// ordered by (bytes k..2k-1, position), and a stable sort of it by the k-gram group of bytes
+// 0..k-1 orders it by the first 2k bytes.  The k positions at the end of the text, which have
+// no position k ahead, take the places of p = 0..k-1 with keys of their own: no search looks
+// at them (a search at level 2k needs 2k bytes after its position and only meets older ones).
+__global__ __launch_bounds__(256) void mf_shift_kernel(const uint32_t *__restrict__ ordk,
+                                                       const uint32_t *__restrict__ gidk, uint32_t n, uint32_t k,
+                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint32_t p = ord8[j];
-        if (p >= 8) {
-            keys[j] = gid8[p - 8];
-            vals[j] = p - 8;
+        const uint32_t p = ordk[j];
+        if (p >= k) {
+            keys[j] = gidk[p - k];
+            vals[j] = p - k;
         } else {
             keys[j] = n + p;
-            vals[j] = n - 8 + p;
+            vals[j] = n - k + p;
         }
     }
 }
 
-// Keys that tell the 16-gram groups apart in the sorted order: (8-gram group of the position,
-// 8-gram group of the position + 8), the latter replaced by a number of its own for the last
-// eight positions of the text.
-__global__ __launch_bounds__(256) void mf_key16_kernel(const uint32_t *__restrict__ ord,
-                                                       const uint32_t *__restrict__ gid8, uint32_t n,
-                                                       uint64_t *__restrict__ keys) {
+// Keys that tell the 2k-gram groups apart in the sorted order: (k-gram group of the position,
+// k-gram group of the position + k), the latter replaced by a number of its own for the last
+// k positions of the text.
+__global__ __launch_bounds__(256) void mf_keydbl_kernel(const uint32_t *__restrict__ ord,
+                                                        const uint32_t *__restrict__ gidk, uint32_t n, uint32_t k,
+                                                        uint64_t *__restrict__ keys) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t i = ord[j];
-        const uint32_t lo = i + 8 < n ? gid8[i + 8] : (0x80000000u | i);
-        keys[j] = ((uint64_t)gid8[i] << 32) | lo;
+        const uint32_t lo = i + k < n ? gidk[i + k] : (0x80000000u | i);
+        keys[j] = ((uint64_t)gidk[i] << 32) | lo;
     }
 }
 
 // ent[j] = {ord[j] (flagged if it is the oldest of its group), 8 bytes at data[ord[j] + sig_off]};
 // rank of ord[j] = j, flagged the same way
-template <int LEVEL, class K>
+template <class K>
 __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__ data, uint32_t n,
                                                      const uint32_t *__restrict__ ord,
                                                      const K *__restrict__ skey, uint32_t sig_off,
-                                                     MfEnt *__restrict__ ent, MfInfo *__restrict__ info,
-                                                     uint32_t wide) {
+                                                     MfEnt *__restrict__ ent, uint32_t *__restrict__ info,
+                                                     uint32_t info_words, uint32_t level, uint32_t wide) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t p = ord[j];
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__
         e.pos = p | first;
         e.sig_lo = (uint32_t)sig, e.sig_hi = (uint32_t)(sig >> 32);
         ent[j] = e;
-        info[p].rank[LEVEL] = lz::mf_rank_word(j, older, wide != 0);
+        info[(size_t)p * info_words + level] = lz::mf_rank_word(j, older, wide != 0);
     }
 }
 
@@ -158,14 +161,14 @@ __global__ __launch_bounds__(256) void mf_ent_kernel(const uint8_t *__restrict__
 // first bytes agree (lz_bin_tree.go:154-172), so a head whose first byte differs is the same
 // as no head; deciding that here (the first byte rides in bits 24..31 of the key, outside the
 // sorted bits) saves the scan two random one-byte reads per position.
-template <int WHICH>
 __global__ __launch_bounds__(256) void mf_prev_kernel(const uint32_t *__restrict__ ord,
                                                       const uint32_t *__restrict__ skey, uint32_t n,
-                                                      MfInfo *__restrict__ info) {
+                                                      uint32_t *__restrict__ info, uint32_t info_words,
+                                                      uint32_t word) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t v = (j > 0 && skey[j - 1] == skey[j]) ? ord[j - 1] : kNone;
-        if (WHICH == 2) info[ord[j]].prev2 = v; else info[ord[j]].prev3 = v;
+        info[(size_t)ord[j] * info_words + word] = v;
     }
 }
 
@@ -259,7 +262,9 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 #ifndef MF_SCAN_WAVES
 #define MF_SCAN_WAVES 4  // 112 registers, no spills: faster than more waves that spill
 #endif
-__global__ __launch_bounds__(64, MF_SCAN_WAVES) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
+// NL: kMfLevels, or kMfMaxLevels when the deep levels were built (more registers: fewer waves)
+template <uint32_t NL>
+__global__ __launch_bounds__(64, NL == lz::kMfLevels ? MF_SCAN_WAVES : 2) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
                                                       uint32_t *__restrict__ arena, uint64_t arena_pairs,
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(64, MF_SCAN_WAVES) void mf_scan_kernel(lz::MfTables
             js = (uint32_t)(job_off[j0 + job] - base), je = (uint32_t)(job_off[j0 + job + 1] - base);
         }
         // pipeline prologue: positions 0 and 1 of the run
-        lz::MfPos a_cur, a_next;
-        lz::MfFront f_cur;
+        lz::MfPos<NL> a_cur, a_next;
+        lz::MfFront<NL> f_cur;
         lz::mf_load_pos(t, p_begin, row_on && p_begin < p_end, a_cur);
         lz::mf_load_front(t, a_cur, row_on && p_begin < p_end, idx, f_cur);
         lz::mf_load_pos(t, p_begin + 1, row_on && p_begin + 1 < p_end, a_next);
@@ -306,9 +311,9 @@ __global__ __launch_bounds__(64, MF_SCAN_WAVES) void mf_scan_kernel(lz::MfTables
             MF_LAP(4)
             // entries of position k + 1 (its record has had a whole step to arrive), then the
             // record of position k + 2
-            lz::MfFront f_next;
+            lz::MfFront<NL> f_next;
             lz::mf_load_front(t, a_next, row_on && P + 1 < p_end, idx, f_next);
-            lz::MfPos a_next2;
+            lz::MfPos<NL> a_next2;
             lz::mf_load_pos(t, P + 2, row_on && P + 2 < p_end && k + 2 < kRowRun, a_next2);
             if (act)
                 while (P >= je) {  // empty jobs are skipped
@@ -429,18 +434,24 @@ size_t MfScratch::tmp_bytes(uint32_t n) {
     return 2 * align256(n1 * 8) + 3 * align256(n1 * 4) + align256(lib_temp_bytes((uint32_t)n1));
 }
 
-int MfScratch::reserve(uint32_t n) {
-    if (n <= cap && cap != 0) return LZMA_AMD_OK;
-    const size_t n1 = n ? n : 1;
-    for (auto &e : ent) LZ_HIP(e.alloc(n1 * sizeof(MfEnt)));
-    LZ_HIP(info.alloc(n1 * sizeof(MfInfo)));
+int MfScratch::reserve(uint32_t n, uint32_t fb) {
+    const uint32_t levels = lz::mf_levels_for(fb, n);
+    if (n <= cap && cap != 0 && levels <= cap_levels) return LZMA_AMD_OK;
+    const size_t n1 = std::max<size_t>(n ? n : 1, cap);
+    const uint32_t lv = std::max(levels, cap_levels);
+    for (uint32_t l = 0; l < lv; l++)
+        if (ent[l].bytes < n1 * sizeof(MfEnt)) LZ_HIP(ent[l].alloc(n1 * sizeof(MfEnt)));
+    // records sized for the deep form once any build needed it
+    const size_t info_bytes = n1 * lz::mf_info_words(lv) * 4;
+    if (info.bytes < info_bytes) LZ_HIP(info.alloc(info_bytes));
     cap = (uint32_t)n1;
+    cap_levels = lv;
     return LZMA_AMD_OK;
 }
 
 int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint32_t fb, hipStream_t st,
                      void *tmp, size_t tmp_cap) {
-    int rc = reserve(n);
+    int rc = reserve(n, fb);
     if (rc) return rc;
     {   // lay out the temporaries
         const size_t n1 = n ? n : 1, need = tmp_bytes(n);
@@ -460,70 +471,71 @@ int MfScratch::build(const uint8_t *d_data, uint32_t n, uint32_t dict_size, uint
     const uint32_t mask = lz::bt4_hash_mask(dict_size);
     view.data = d_data;
     view.n = n;
-    for (uint32_t l = 0; l < lz::kMfLevels; l++) view.ent[l] = ent[l].as<MfEnt>();
-    view.info = info.as<MfInfo>();
+    for (uint32_t l = 0; l < lz::kMfMaxLevels; l++) view.ent[l] = ent[l].as<MfEnt>();
+    view.info = info.p;
     view.dict = dict_size;
     view.fb = fb;
-    view.levels = 1;
-    while (view.levels < lz::kMfLevels && fb >= lz::mf_known(view.levels)) view.levels++;
-    if (n < 32) view.levels = 1;  // too short for any search to use the finer groups' shift by 8
+    view.levels = lz::mf_levels_for(fb, n);
     view.packed = lz::mf_can_pack(dict_size) ? 1u : 0u;
     view.wide = n > lz::kMfClassMax ? 1u : 0u;
     if (n == 0) return LZMA_AMD_OK;
 
     const unsigned g = grid_for(n, 256);
-    MfEnt *e0 = ent[0].as<MfEnt>(), *e1 = ent[1].as<MfEnt>(), *e2 = ent[2].as<MfEnt>(), *e3 = ent[3].as<MfEnt>();
-    MfInfo *inf = info.as<MfInfo>();
+    uint32_t *inf = info.as<uint32_t>();
+    const uint32_t iw = lz::mf_info_words(view.levels), ip = lz::mf_info_prev(view.levels);
     uint32_t *ord = (uint32_t *)vout;
     // level 0: hash-4 buckets
     hipLaunchKernelGGL((mf_key_kernel<KEY4, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, mask,
                        (uint32_t *)kin);
     if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, bits_of(mask), st))) return rc;
-    hipLaunchKernelGGL((mf_ent_kernel<0, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                       (const uint32_t *)kout, 0u, e0, inf, view.wide);
+    hipLaunchKernelGGL(mf_ent_kernel<uint32_t>, dim3(g), dim3(256), 0, st, d_data, n, ord,
+                       (const uint32_t *)kout, 0u, ent[0].as<MfEnt>(), inf, iw, 0u, view.wide);
     // level 1: 6-gram groups
     if (view.levels > 1) {
         hipLaunchKernelGGL((mf_key_kernel<KEY6, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            (uint64_t *)kin);
         if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 48, st))) return rc;
-        hipLaunchKernelGGL((mf_ent_kernel<1, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kout, 6u, e1, inf, view.wide);
+        hipLaunchKernelGGL(mf_ent_kernel<uint64_t>, dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kout, 6u, ent[1].as<MfEnt>(), inf, iw, 1u, view.wide);
     }
     // level 2: 8-gram groups
     if (view.levels > 2) {
         hipLaunchKernelGGL((mf_key_kernel<KEY8, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                            (uint64_t *)kin);
         if ((rc = sort_by_key(*this, (uint64_t *)kin, (uint64_t *)kout, ord, n, 64, st))) return rc;
-        hipLaunchKernelGGL((mf_ent_kernel<2, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kout, 8u, e2, inf, view.wide);
+        hipLaunchKernelGGL(mf_ent_kernel<uint64_t>, dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kout, 8u, ent[2].as<MfEnt>(), inf, iw, 2u, view.wide);
     }
-    // level 3: 16-gram groups, from the 8-gram order (see mf_shift16_kernel)
-    if (view.levels > 3) {
-        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (const uint64_t *)kout, n,
-                           (uint32_t *)grp);
+    // levels 3..: groups of 16, 32, 64, 128 bytes, each from the order of the level before it
+    // (see mf_shift_kernel).  `ord` is that order and `sorted` its keys in sorted order.
+    const uint64_t *sorted = (const uint64_t *)kout;
+    for (uint32_t l = 3; l < view.levels; l++) {
+        const uint32_t k = lz::mf_known(l) / 2;
+        hipLaunchKernelGGL(mf_head_kernel<uint64_t>, dim3(g), dim3(256), 0, st, sorted, n, (uint32_t *)grp);
         if ((rc = max_scan(*this, (uint32_t *)grp, n, st))) return rc;
         hipLaunchKernelGGL(mf_gid_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)grp, n, (uint32_t *)gid);
         // keys and values of the sort share the key-input area (32-bit keys leave half of it free)
-        uint32_t *k16 = (uint32_t *)kin, *v16 = (uint32_t *)kin + n;
-        hipLaunchKernelGGL(mf_shift16_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n, k16, v16);
-        // the sorted keys name the 16-gram groups only together with the bytes 8..15 order, so the
-        // group boundaries are found from the pair (key, 8-gram group of the position + 8) below
-        if ((rc = sort_vals_by_key(*this, k16, (uint32_t *)kout, v16, ord, n, bits_of((uint64_t)n + 8), st)))
+        uint32_t *k32 = (uint32_t *)kin, *v32 = (uint32_t *)kin + n;
+        hipLaunchKernelGGL(mf_shift_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n, k, k32, v32);
+        // the sorted keys name the 2k-gram groups only together with the bytes k..2k-1 order, so the
+        // group boundaries are found from the pair (key, k-gram group of the position + k) below
+        if ((rc = sort_vals_by_key(*this, k32, (uint32_t *)kout, v32, ord, n, bits_of((uint64_t)n + k), st)))
             return rc;
-        hipLaunchKernelGGL(mf_key16_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n,
+        hipLaunchKernelGGL(mf_keydbl_kernel, dim3(g), dim3(256), 0, st, ord, (const uint32_t *)gid, n, k,
                            (uint64_t *)kin);
-        hipLaunchKernelGGL((mf_ent_kernel<3, uint64_t>), dim3(g), dim3(256), 0, st, d_data, n, ord,
-                           (const uint64_t *)kin, 16u, e3, inf, view.wide);
+        hipLaunchKernelGGL(mf_ent_kernel<uint64_t>, dim3(g), dim3(256), 0, st, d_data, n, ord,
+                           (const uint64_t *)kin, lz::mf_known(l), ent[l].as<MfEnt>(), inf, iw, l, view.wide);
+        sorted = (const uint64_t *)kin;
     }
     // hash-3 and hash-2 heads
     hipLaunchKernelGGL((mf_key_kernel<KEY3, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        (uint32_t *)kin);
     if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, 16, st))) return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<3>, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf);
+    hipLaunchKernelGGL(mf_prev_kernel, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf, iw, ip + 1);
     hipLaunchKernelGGL((mf_key_kernel<KEY2, uint32_t>), dim3(g), dim3(256), 0, st, d_data, n, 0u,
                        (uint32_t *)kin);
     if ((rc = sort_by_key(*this, (uint32_t *)kin, (uint32_t *)kout, ord, n, 10, st))) return rc;
-    hipLaunchKernelGGL(mf_prev_kernel<2>, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf);
+    hipLaunchKernelGGL(mf_prev_kernel, dim3(g), dim3(256), 0, st, ord, (uint32_t *)kout, n, inf, iw, ip);
     LZ_HIP(hipGetLastError());
     return LZMA_AMD_OK;
 }
@@ -571,9 +583,14 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
     const uint64_t nrows = (uint64_t)blocks * 16;  // 16-lane rows, each with an arena page of its own
     for (int attempt = 0; attempt < 8; attempt++) {
         LZ_HIP(hipMemsetAsync(r.ctrl.p, 0, 3 * 8, st));
-        hipLaunchKernelGGL(mf_scan_kernel, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off, base, j0,
-                           njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
-                           r.ctrl.as<unsigned long long>());
+        if (s.view.levels > lz::kMfLevels)
+            hipLaunchKernelGGL(mf_scan_kernel<lz::kMfMaxLevels>, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off,
+                               base, j0, njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
+                               r.ctrl.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL(mf_scan_kernel<lz::kMfLevels>, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off,
+                               base, j0, njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
+                               r.ctrl.as<unsigned long long>());
         LZ_HIP(hipGetLastError());
         unsigned long long h[3];
         LZ_HIP(hipMemcpyAsync(h, r.ctrl.p, sizeof h, hipMemcpyDeviceToHost, st));

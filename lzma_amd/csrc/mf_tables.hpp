@@ -17,9 +17,10 @@ namespace lzh {
 constexpr uint32_t kMfPagePairs = 4096;  // arena page: pairs a 16-lane row appends to before taking a new page
 
 struct MfScratch {
-    DevBuf ent[lz::kMfLevels], info; // tables (see lzma_mf_core.hpp)
+    DevBuf ent[lz::kMfMaxLevels], info; // tables (see lzma_mf_core.hpp)
     DevBuf own_tmp;                 // temporaries, when the caller lends no memory for them
     uint32_t cap = 0;               // positions the tables hold
+    uint32_t cap_levels = 0;        // levels they hold
     lz::MfTables view;
     // temporaries of one build: sort keys in/out, sorted positions, group starts, library scratch
     void *kin = nullptr, *kout = nullptr, *vout = nullptr, *grp = nullptr, *gid = nullptr, *temp = nullptr;
@@ -27,8 +28,8 @@ struct MfScratch {
     // No encode kernel is resident while this build's sorts run: they may use the library's
     // single-pass radix sort (see matchfinder.hip).  Set by the caller before build().
     bool alone = false;
-    // Makes room for the tables of batches of up to n positions (n < 2^32 - 64).
-    int reserve(uint32_t n);
+    // Makes room for the tables of batches of up to n positions (n < 2^32 - 64) searched up to fb bytes.
+    int reserve(uint32_t n, uint32_t fb);
     // Bytes of temporaries a build of n positions needs.
     static size_t tmp_bytes(uint32_t n);
     // Makes sure builds of up to n positions find their temporaries without allocating.
@@ -46,7 +47,7 @@ struct MfScratch {
     void release() {
         for (auto &e : ent) e.release();
         info.release(), own_tmp.release();
-        cap = 0;
+        cap = 0, cap_levels = 0;
     }
     uint64_t bytes() const {
         uint64_t b = info.bytes + own_tmp.bytes;
@@ -55,8 +56,8 @@ struct MfScratch {
     }
     // table bytes per position (temporaries not included)
     static uint64_t bytes_per_position(uint32_t fb) {
-        (void)fb;
-        return lz::kMfLevels * sizeof(lz::MfEnt) + sizeof(lz::MfInfo);
+        const uint32_t levels = lz::mf_levels_for(fb, 1u << 30);
+        return levels * sizeof(lz::MfEnt) + lz::mf_info_words(levels) * 4;
     }
 };
 

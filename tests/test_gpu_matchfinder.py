@@ -52,3 +52,33 @@ def test_random_bytes_and_runs():
 def test_tiny(n, data_txt):
     _check(data_txt[:n], 1 << 20, 64)
     _check(b"a" * n, 1 << 12, 32)
+
+
+def _mutated_repeats(n, block, seed):
+    """Blocks of `block` random bytes repeated with a few bytes changed per copy: common
+    prefixes of every length up to the block size, groups of thousands of positions."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(97, 123, block, dtype=np.uint8)
+    out = np.tile(base, n // block + 1)[:n].copy()
+    hits = rng.integers(0, n, n // 97)
+    out[hits] = rng.integers(97, 123, hits.size, dtype=np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("block,fb", [(400, 273), (150, 273), (70, 256), (33, 273), (400, 255)])
+def test_deep_groups(block, fb):
+    """Searches of 256 bytes and more use the 32-, 64- and 128-byte groups (fb 255: they are
+    not built); the data has matches on both sides of each of those lengths."""
+    _check(_mutated_repeats(300000, block, block), 1 << 20, fb)
+
+
+@pytest.mark.parametrize("n", [31, 32, 63, 64, 127, 128, 255, 256, 511, 512, 513, 1100])
+def test_deep_levels_short_texts(n):
+    """Texts around the lengths at which a deep level starts to be built."""
+    _check(_mutated_repeats(n, 37, n), 1 << 16, 273)
+    _check(b"ab" * (n // 2), 1 << 16, 273)
+
+
+def test_runs_at_full_length():
+    _check(np.concatenate([np.zeros(5000, np.uint8), _mutated_repeats(20000, 300, 5), np.zeros(3000, np.uint8)]),
+           1 << 12, 273)
