@@ -164,9 +164,9 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         e.run(small);
 #if defined(LZ_PROFILE)
         if (lane == 0 && blockIdx.x == 0)
-            printf("PROF chunk n=%u: mf %llu | path %llu | prices %llu | round %llu | lit %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | getopt_other %llu | emit %llu\n",
+            printf("PROF chunk n=%u: mf %llu | path %llu | prices %llu | round-loads %llu | round %llu | lit %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | getopt_other %llu | emit %llu\n",
                    e.n, (unsigned long long)e.prof[0], (unsigned long long)e.prof[8], (unsigned long long)e.prof[1],
-                   (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[10],
+                   (unsigned long long)e.prof[11], (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[10],
                    (unsigned long long)e.prof[3], (unsigned long long)e.prof[4], (unsigned long long)e.prof[5],
                    (unsigned long long)e.prof[6], (unsigned long long)e.prof[7]);
 #endif

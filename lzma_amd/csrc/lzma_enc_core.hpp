@@ -312,8 +312,10 @@ struct Encoder {
         return r;
     }
     LZ_HD Reps gbks(uint32_t i) const {
-        Reps r;
-        if (in_bwin(i)) r = o_bks[i & (kBksWin - 1)]; else r = opt_g[i].bks;
+        // the LDS slot is read in any case and replaced under a branch: one pointer chosen between
+        // the two memories would make every one of these reads a generic-address load
+        Reps r = o_bks[i & (kBksWin - 1)];
+        if (!in_bwin(i)) r = opt_g[i].bks;
         return r;
     }
     LZ_HD void sbks(uint32_t i, const Reps &v) {  // only ever written at cur
@@ -1123,6 +1125,10 @@ struct Encoder {
                         const uint64_t a0 = enc_load8(a), b0 = enc_load8(b), a1 = enc_load8(a + 8), b1 = enc_load8(b + 8);
                         const uint32_t pv = a[-1];
                         const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+#if defined(LZ_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" ::"v"(x0), "v"(x1), "v"(pv));
+                        LZ_LAP(11)
+#endif
                         // equal bytes from offset `from` inside the 16 fetched (16 - from if all equal)
                         auto run16 = [&](uint32_t from) -> uint32_t {
                             if (from >= 16) return 0;
