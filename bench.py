@@ -574,23 +574,28 @@ class StubWorkload:
         return {"workload": "stub (rank plumbing only)", "chunks_total": self.total}
 
 
-def timed(wl, steps, warmup, world, dev):
-    for _ in range(warmup):
+def note(msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    print(f"[bench {time.perf_counter() - T_START:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
+def timed(wl, steps, warmup, world, dev, quiet=False):
+    # a progress line per step on stderr (no device synchronization: steps of workloads that
+    # return before the device is done are not held up by it)
+    say = (lambda m: None) if (quiet or int(os.environ.get("RANK", "0")) != 0) else note
+    for i in range(warmup):
         wl.step()
+        say(f"warm-up step {i + 1}/{warmup}")
     barrier_sync(world, dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         wl.step()
+        say(f"step {i + 1}/{steps}")
     barrier_sync(world, dev)
     dt = time.perf_counter() - t0
     dt = reduce_ranks(dt, world, dev, "MAX")
     units = reduce_ranks(float(wl.units()), world, dev, "SUM") * steps
     return dt, units
-
-
-def note(msg):
-    """Progress on stderr (stdout carries the one JSON line)."""
-    print(f"[bench {time.perf_counter() - T_START:6.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
 def extra_leg(name, make, budget_s):
@@ -602,7 +607,7 @@ def extra_leg(name, make, budget_s):
         wl = make()
         dev = wl.dev
         note(f"{name}: inputs ready")
-        dt, units = timed(wl, 2, 1, 1, dev)
+        dt, units = timed(wl, 2, 1, 1, dev, quiet=True)
         wl.verify()
         note(f"{name}: timed and verified")
         out = {"value": round(units / dt / 1e6, 3), "unit": "MB/s", "steps": 2, "warmup": 1,
