@@ -297,9 +297,9 @@ int launch_encode(unsigned grid, unsigned lds, hipStream_t es, const uint8_t *da
 }  // namespace
 
 // The call is cut into batches of whole chunks.  The finder works through the batches on
-// one stream; each batch's encode launch goes to one of kEncStreams other streams as soon
-// as its match lists are complete, so that up to kEncStreams launches (together as many
-// chunks as the device holds at once) run while the finder prepares the next batch.
+// one stream; the batches' encode launches go to kEncStreams other streams: one of them runs
+// beside the finder, the others start together when the finder has done its last batch (see
+// "Launch order" below), together as many chunks as the device holds at once.
 extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off,
                                           size_t n_chunks, size_t in_total, const lzma_amd_params *p,
                                           uint8_t *d_out, const uint64_t *d_out_off,
@@ -360,7 +360,6 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
 
     lzh::release_finder_workspace();  // what a match-finder call of this thread kept is needed here
     int enc_streams = kEncStreams;
-    const bool sort_alone = getenv("LZMA_AMD_SORT_ALONE") != nullptr;  // experiment: single-pass sorts next to encode launches
     if (const char *e = getenv("LZMA_AMD_ENC_STREAMS")) enc_streams = std::max(1, std::min(atoi(e), (int)kEncStreams));
     // with many chunks a batch holds the resident workgroups' share of one launch, so that
     // the launches in flight fill the device exactly; few or small chunks are batched by size
@@ -516,7 +515,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         t_mf[b].start(S.mf);
         // the sort temporaries live in the arena the scan is about to fill when it is large
         // enough; the first batch's sorts run before any encode launch of this call
-        scratch.alone = b == 0 || sort_alone;
+        scratch.alone = b == 0;
         if ((rc = scratch.build(d_in + base, nbytes, ep.dict_size, ep.fb, S.mf, sl.res.arena.p,
                                 sl.res.arena.bytes)))
             return bail(rc);
