@@ -141,3 +141,41 @@ def test_c5_shape_full_chunk():
     assert outs[1] == want
     ref = O.encode(small, O.params(dict_log=26, fb=273, lc=3, lp=0, pb=2, cut=0, eos=False))
     assert len(outs[1]) <= 1.01 * len(ref), (len(outs[1]), len(ref))
+
+
+@pytest.mark.parametrize("co_run", ["0", "1", "3"])
+def test_many_batches_every_launch_order(co_run):
+    """A call cut into nine small batches (more than there are match-list slots, so slots are
+    reused and waiting batches have to be launched to free them), with none, one or every
+    finished batch launched beside the finder.  In a child process: the settings are read per call
+    but the workspace is sized by the first one."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import lzma_amd
+from oracle import oracle as O
+from tests import synth
+n_chunks, chunk = 36, 1 << 18
+buf = synth.markov(n_chunks * chunk)
+chunks = [bytes(buf[i * chunk:(i + 1) * chunk]) for i in range(n_chunks)]
+chunks[5] = b""
+chunks[-1] = chunks[-1][:777]
+p = lzma_amd.make_params(20, 64)
+from lzma_amd import _native as N
+st, outs = lzma_amd.encode_chunks(chunks, p)
+assert (st == 0).all()
+assert N.last_timing()["coder_launches"] == 9, N.last_timing()
+st2, dec = lzma_amd.decode_batch(outs)
+assert (st2 == 0).all() and dec == chunks
+for i in (0, 4, 5, 17, 35):
+    want = O.encode(chunks[i], O.params(dict_log=20, fb=64, lc=3, lp=0, pb=2, cut=1 << 30, eos=False))
+    assert outs[i] == want, i
+print("batches ok")
+'''
+    env = dict(os.environ, LZMA_AMD_BATCH_MIB="1", LZMA_AMD_CO_RUN=co_run)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "batches ok" in r.stdout, r.stdout + r.stderr
