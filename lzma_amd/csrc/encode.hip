@@ -464,9 +464,12 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     // Launch order.  A resident encode wave holds a third of a SIMD's registers, so every launch
     // running beside the finder takes waves away from it: with one launch beside it a finder
     // batch takes 1.4 times as long as alone, with two 2.4 times (measured, 1 MiB chunks).  A
-    // chunk's encode time hardly depends on what else runs.  So while the finder has batches
-    // left, one launch runs beside it and the other finished batches wait; they start together
-    // when the finder is done, or when every match-list slot is taken.
+    // chunk's encode time hardly depends on what else runs.  The end of a call is what this
+    // costs most: the call ends one chunk time after the finder's last batch.  So once the
+    // chunks not yet launched fit the device together (the call's last generation), at most one
+    // launch runs beside the finder and the other finished batches wait; they start together when
+    // the finder is done, or when every match-list slot is taken.  Before that, every batch is
+    // launched as soon as its lists are complete.
     struct Held {
         size_t b;
         uint64_t base;
@@ -529,8 +532,9 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         // the next batch's slot still holds the lists of a batch that waits: the slots have run out
         bool slots_full = false;
         for (const Held &h : held) slots_full |= h.b % nslots == (b + 1) % nslots;
+        const bool last_generation = n_chunks - cut[held.front().b] <= resident;
         size_t n_launch = 0;
-        if (finder_done || slots_full)
+        if (finder_done || slots_full || !last_generation)
             n_launch = held.size();
         else {
             const int r = running();
