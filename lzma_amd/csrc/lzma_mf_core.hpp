@@ -354,7 +354,9 @@ LZ_D void mf_level(const MfTables &t, const MfEnt *tab, uint32_t top, uint32_t f
 // act == false take no part.  Returns the row's number of pairs; the pairs themselves are
 // written through `out` (a later pair with a smaller index overwrites: the reference drops
 // seed pairs that way).
-template <uint32_t NL>
+// TINY: the text is too short for any level but the buckets (mf_levels_for), whose candidates
+// then share more than the 8 bytes their entries carry.
+template <uint32_t NL, bool TINY>
 LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos<NL> &a, const MfFront<NL> &f, uint32_t job_start,
                        uint32_t job_end, bool act, const MfRowOut &out, uint32_t lane MF_PROF_ARG) {
     const uint32_t idx = lane & 15u, row_base = lane & 48u;
@@ -423,9 +425,9 @@ LZ_D uint32_t mf_find4(const MfTables &t, uint32_t P, const MfPos<NL> &a, const 
         // candidates of this level share fewer bytes than the next level's groups do
         const uint32_t ceil = (l + 1 < NL && l + 1 < t.levels && len_limit >= mf_known(l + 1))
                                   ? mf_known(l + 1) - 1 : len_limit;
-        // candidates can share more than the 8 bytes their entries carry from 16 bytes on, and at
-        // the last level built (a text too short for the finer levels)
-        mf_level(t, t.ent[l], top[l], fetched[l], f.e[l], low, psig, mf_known(l), l >= 3 || l + 1 >= t.levels, P, len_limit, ceil,
+        // candidates can share more than the 8 bytes their entries carry from 16 bytes on (below
+        // that the next level, or fb, ends them first)
+        mf_level(t, t.ent[l], top[l], fetched[l], f.e[l], low, psig, mf_known(l), l >= 3 || TINY, P, len_limit, ceil,
                  n, max_len, fin, go[l], out, lane MF_PROF_PASS);
     }
     return n;

@@ -218,19 +218,196 @@ int sort_pairs_cfg(lzh::MfScratch &s, K *keys_in, K *keys_out, V vals_in, uint32
     return LZMA_AMD_OK;
 }
 
+// ---- the finder's own radix sort, for batches sorted while encode launches are resident.
+// Least significant digit first, 8 bits per pass, three kernels per pass and no dependence
+// between workgroups inside a kernel (nothing spins on another workgroup's progress, which is
+// what the library's single-pass sort does and what stalls it beside long-running waves):
+//   1. every workgroup counts the digits of its tile of kRsTile consecutive items;
+//   2. an exclusive scan over the counts in (digit, tile) order gives every tile the place
+//      where its items of each digit start;
+//   3. every workgroup sorts its tile by the digit inside LDS -- each wave takes a quarter of
+//      the tile 64 items at a time, the lanes holding the same digit find each other with
+//      eight ballots and take consecutive ranks behind the wave's running count for that
+//      digit; the waves' counts are then stacked in wave order -- and writes the sorted tile
+//      out, so that the items of one digit go to consecutive addresses in one piece.
+// Stable, so the passes compose.
+constexpr uint32_t kRsTile = 2048, kRsThreads = 256, kRsPerThread = kRsTile / kRsThreads;
+
+template <class K>
+__global__ __launch_bounds__(kRsThreads) void rs_count_kernel(const K *__restrict__ keys, uint32_t n, uint32_t shift,
+                                                              uint32_t *__restrict__ counts, uint32_t ntiles) {
+    __shared__ uint32_t h[256];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = tile * kRsTile;
+#pragma unroll
+    for (uint32_t s = 0; s < kRsPerThread; s++) {
+        const uint32_t i = base + s * kRsThreads + tid;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)tid * ntiles + tile] = h[tid];
+}
+
+template <class K>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                                K *__restrict__ kout, uint32_t *__restrict__ vout,
+                                                                uint32_t n, uint32_t shift,
+                                                                const uint32_t *__restrict__ starts, uint32_t ntiles) {
+    constexpr uint32_t kWaves = kRsThreads / 64, kWaveItems = kRsTile / kWaves;
+    __shared__ K sk[kRsTile];
+    __shared__ uint32_t sv[kRsTile];
+    __shared__ uint32_t wcount[kWaves][256];  // per wave: items of each digit, then where they start in the tile
+    __shared__ uint32_t dstart[256], gstart[256], wsum[kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, tile = blockIdx.x;
+    const uint32_t base = tile * kRsTile;
+    const uint32_t cnt = n - base < kRsTile ? n - base : kRsTile;
+#pragma unroll
+    for (uint32_t i = 0; i < kWaves; i++) wcount[i][tid] = 0;
+    gstart[tid] = starts[(size_t)tid * ntiles + tile];
+    // the wave's items, 64 consecutive ones per step: all requested at once
+    K k[kRsPerThread];
+    uint32_t v[kRsPerThread], r[kRsPerThread];
+#pragma unroll
+    for (uint32_t s = 0; s < kRsPerThread; s++) {
+        const uint32_t j = w * kWaveItems + s * 64 + lane;  // index in the tile
+        k[s] = (K)0, v[s] = 0;
+        if (j < cnt) {
+            k[s] = kin[base + j];
+            v[s] = vin ? vin[base + j] : base + j;
+        }
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t s = 0; s < kRsPerThread; s++) {
+        const bool valid = w * kWaveItems + s * 64 + lane < cnt;
+        const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (uint32_t b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        r[s] = wcount[w][d] + (uint32_t)__builtin_popcountll(same & below);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the lanes' reads come before the update
+        if (valid && (same >> lane) == 1ull) wcount[w][d] += (uint32_t)__builtin_popcountll(same);  // the group's last lane
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __syncthreads();
+    // thread d: the waves' counts of digit d stacked in wave order, then the digits in order
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kWaves; i++) {
+        const uint32_t c = wcount[i][tid];
+        wcount[i][tid] = total;
+        total += c;
+    }
+    uint32_t inc = total;  // inclusive scan over the wave's 64 digits
+#pragma unroll
+    for (uint32_t o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, (int)o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kWaves; i++)
+        if (i < w) before += wsum[i];
+    dstart[tid] = before + inc - total;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t s = 0; s < kRsPerThread; s++) {
+        if (w * kWaveItems + s * 64 + lane < cnt) {
+            const uint32_t d = (uint32_t)(k[s] >> shift) & 255u;
+            const uint32_t at = dstart[d] + wcount[w][d] + r[s];
+            sk[at] = k[s];
+            sv[at] = v[s];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += kRsThreads) {
+        const K key = sk[i];
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        const uint32_t at = gstart[d] + (i - dstart[d]);
+        kout[at] = key;
+        vout[at] = sv[i];
+    }
+}
+
+size_t rs_scan_temp_bytes(uint32_t ncounts) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, ncounts,
+                                  rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
+    return bytes;
+}
+// bytes of temporaries own_sort_pairs needs for n items
+size_t rs_temp_bytes(uint32_t n) {
+    const uint32_t ntiles = (n + kRsTile - 1) / kRsTile;
+    const size_t a = ((size_t)n * 4 + 255) & ~(size_t)255, b = ((size_t)ntiles * 256 * 4 + 255) & ~(size_t)255;
+    return a + b + rs_scan_temp_bytes(ntiles * 256) + 256;
+}
+
+// keys_in is used as the second key buffer and does not survive; vals_in == nullptr stands
+// for the values 0..n-1.
+template <class K>
+int own_sort_pairs(lzh::MfScratch &s, K *keys_in, K *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                   uint32_t n, unsigned end_bit, hipStream_t st) {
+    if (rs_temp_bytes(n) > s.temp_bytes) return lzh::fail(LZMA_AMD_ERR_NOMEM, "match finder: sort scratch underestimated");
+    const uint32_t ntiles = (n + kRsTile - 1) / kRsTile, ncounts = ntiles * 256;
+    uint8_t *q = (uint8_t *)s.temp;
+    uint32_t *vtmp = (uint32_t *)q;
+    q += ((size_t)n * 4 + 255) & ~(size_t)255;
+    uint32_t *counts = (uint32_t *)q;
+    q += ((size_t)ncounts * 4 + 255) & ~(size_t)255;
+    size_t scan_bytes = s.temp_bytes - (size_t)(q - (uint8_t *)s.temp);
+    const unsigned passes = (end_bit + 7) / 8;
+    K *kc = keys_in, *kn = keys_out;
+    const uint32_t *vc = vals_in;
+    for (unsigned p = 0; p < passes; p++) {
+        // the last pass writes vals_out, the one before it the temporary, and so on back
+        uint32_t *vn = ((passes - 1 - p) & 1u) ? vtmp : vals_out;
+        hipLaunchKernelGGL(rs_count_kernel<K>, dim3(ntiles), dim3(kRsThreads), 0, st, (const K *)kc, n, 8 * p, counts, ntiles);
+        size_t bytes = scan_bytes;
+        LZ_HIP(rocprim::exclusive_scan(q, bytes, counts, counts, 0u, ncounts, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(ntiles), dim3(kRsThreads), 0, st, (const K *)kc, vc, kn, vn, n, 8 * p,
+                           (const uint32_t *)counts, ntiles);
+        std::swap(kc, kn);
+        vc = vn;
+    }
+    // an even number of passes leaves the keys in keys_in
+    if (kc != keys_out) LZ_HIP(hipMemcpyAsync(keys_out, kc, (size_t)n * sizeof(K), hipMemcpyDeviceToDevice, st));
+    LZ_HIP(hipGetLastError());
+    return LZMA_AMD_OK;
+}
+
+// LZMA_AMD_SORT=merge: the library's merge sort instead of the finder's own radix sort beside
+// resident encode launches (for comparison)
+bool use_own_sort() {
+    static const bool own = [] {
+        const char *e = getenv("LZMA_AMD_SORT");
+        return !(e && strcmp(e, "merge") == 0);
+    }();
+    return own;
+}
+
 // values out = the positions 0..n-1 ordered by key
 template <class K>
 int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n,
                 unsigned end_bit, hipStream_t st) {
     rocprim::counting_iterator<uint32_t> iota(0);
-    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st)
-                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
+    if (s.alone) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
+    if (use_own_sort()) return own_sort_pairs<K>(s, keys_in, keys_out, nullptr, vals_out, n, end_bit, st);
+    return sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
 }
 // values out = vals_in ordered by key (stable)
 int sort_vals_by_key(lzh::MfScratch &s, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
                      uint32_t *vals_out, uint32_t n, unsigned end_bit, hipStream_t st) {
-    return s.alone ? sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st)
-                   : sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
+    if (s.alone) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
+    if (use_own_sort()) return own_sort_pairs<uint32_t>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
+    return sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
 }
 
 int max_scan(lzh::MfScratch &s, uint32_t *io, uint32_t n, hipStream_t st) {
@@ -262,8 +439,9 @@ constexpr uint32_t kRowRun = 64;   // ... of which each 16-lane row takes a quar
 #ifndef MF_SCAN_WAVES
 #define MF_SCAN_WAVES 4  // 112 registers, no spills: faster than more waves that spill
 #endif
-// NL: kMfLevels, or kMfMaxLevels when the deep levels were built (more registers: fewer waves)
-template <uint32_t NL>
+// NL: kMfLevels, or kMfMaxLevels when the deep levels were built (more registers: fewer waves);
+// TINY: a text of fewer than 32 bytes (see mf_find4)
+template <uint32_t NL, bool TINY>
 __global__ __launch_bounds__(64, NL == lz::kMfLevels ? MF_SCAN_WAVES : 2) void mf_scan_kernel(lz::MfTables t, const uint64_t *__restrict__ job_off,
                                                       uint64_t base, uint64_t j0, uint32_t njobs,
                                                       uint64_t *__restrict__ meta,
@@ -342,7 +520,7 @@ __global__ __launch_bounds__(64, NL == lz::kMfLevels ? MF_SCAN_WAVES : 2) void m
             out.packed = t.packed != 0;
             out.dst = arena + (out.packed ? cursor : 2 * cursor);
             out.on = act && !overflow;
-            const uint32_t c = lz::mf_find4(t, P, a_cur, f_cur, js, je, act, out, lane MF_PROF_PASS);
+            const uint32_t c = lz::mf_find4<NL, TINY>(t, P, a_cur, f_cur, js, je, act, out, lane MF_PROF_PASS);
             if (act) {
                 if (idx == 0) meta[P] = lz::mf_meta(cursor, c);
                 if (!overflow) cursor += c;
@@ -426,6 +604,7 @@ static size_t lib_temp_bytes_cfg(uint32_t n) {
 static size_t lib_temp_bytes(uint32_t n) {  // largest request of any sort or scan of n items
     size_t t = std::max(lib_temp_bytes_cfg<MergeCfg>(n), lib_temp_bytes_cfg<AloneCfg>(n));
     t = std::max(t, scan_temp_bytes(n));
+    t = std::max(t, rs_temp_bytes(n));
     return t + 256;
 }
 
@@ -583,14 +762,17 @@ int mf_scan(const MfScratch &s, MfResult &r, const uint64_t *d_job_off, uint64_t
     const uint64_t nrows = (uint64_t)blocks * 16;  // 16-lane rows, each with an arena page of its own
     for (int attempt = 0; attempt < 8; attempt++) {
         LZ_HIP(hipMemsetAsync(r.ctrl.p, 0, 3 * 8, st));
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off, base, j0, njobs,
+                               r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
+                               r.ctrl.as<unsigned long long>());
+        };
         if (s.view.levels > lz::kMfLevels)
-            hipLaunchKernelGGL(mf_scan_kernel<lz::kMfMaxLevels>, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off,
-                               base, j0, njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
-                               r.ctrl.as<unsigned long long>());
+            launch(mf_scan_kernel<lz::kMfMaxLevels, false>);
+        else if (n < 32)
+            launch(mf_scan_kernel<lz::kMfLevels, true>);
         else
-            hipLaunchKernelGGL(mf_scan_kernel<lz::kMfLevels>, dim3(blocks * 4), dim3(64), 0, st, s.view, d_job_off,
-                               base, j0, njobs, r.meta.as<uint64_t>(), r.arena.as<uint32_t>(), r.arena_pairs,
-                               r.ctrl.as<unsigned long long>());
+            launch(mf_scan_kernel<lz::kMfLevels, false>);
         LZ_HIP(hipGetLastError());
         unsigned long long h[3];
         LZ_HIP(hipMemcpyAsync(h, r.ctrl.p, sizeof h, hipMemcpyDeviceToHost, st));

@@ -31,7 +31,7 @@ for r in step:
         print(f"  batch {batch_start:9.1f}: sorts {acc['sort']:7.1f}  tables {acc['table']:7.1f}  scan {s:9.1f} {e:9.1f} {e - s:8.1f}  (batch {e - batch_start:7.1f})")
         acc = {"sort": 0.0, "table": 0.0}
         batch_start = None
-    elif "rocprim" in name or "mf_" in name:
+    elif "rocprim" in name or "mf_" in name or "rs_" in name or "copyBuffer" in name:
         if batch_start is None:
             batch_start = s
-        acc["sort" if "rocprim" in name else "table"] += e - s
+        acc["table" if "mf_" in name else "sort"] += e - s
