@@ -26,6 +26,8 @@ def kernel_class(name):
         return "encode_kernel"
     if "mf_scan" in name:
         return "mf_scan_kernel"
+    if "rs_" in name:
+        return "mf_radix_sort_kernels"
     if "rocprim" in name:
         return "rocprim_sorts_and_scans"
     if "mf_" in name:
@@ -35,7 +37,7 @@ def kernel_class(name):
 
 def short_name(name):
     """Kernel names without argument lists; library kernels by their rocprim entry point and key type."""
-    m = re.search(r"(encode_kernel|decode_kernel<\w+>|mf_\w+_kernel(<[^>]*>)?)", name)
+    m = re.search(r"(encode_kernel|decode_kernel<\w+>|(mf|rs)_\w+_kernel(<[^>]*>)?)", name)
     if m:
         return m.group(1)
     m = re.search(r"wrapped_(\w+?)_config<[^;,]*[;,] *unsigned (long|int)", name)
@@ -175,7 +177,9 @@ def counters(run, prof, tag, chunks):
             out[k]["launches"] = calls[k]
     n_in = chunks << 20
     rows = {}
-    for k in ("encode_kernel", "mf_scan_kernel", "rocprim_sorts_and_scans", "mf_table_kernels"):
+    for k in ("encode_kernel", "mf_scan_kernel", "rocprim_sorts_and_scans", "mf_radix_sort_kernels", "mf_table_kernels"):
+        if k not in out:
+            continue  # (the finder's own sort only runs beside encode launches: not in a single-batch run)
         v = out[k]
         rows[k] = {
             "launches": v["launches"], "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
