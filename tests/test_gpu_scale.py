@@ -155,6 +155,7 @@ def test_many_batches_every_launch_order(co_run):
     code = r'''
 import os, sys
 sys.path.insert(0, os.getcwd())
+import numpy as np
 import lzma_amd
 from oracle import oracle as O
 from tests import synth
@@ -163,6 +164,10 @@ buf = synth.markov(n_chunks * chunk)
 chunks = [bytes(buf[i * chunk:(i + 1) * chunk]) for i in range(n_chunks)]
 chunks[5] = b""
 chunks[-1] = chunks[-1][:777]
+# keys that are all equal, and keys with no structure, for the sorts of the batches that hold them
+chunks[9] = bytes(chunk)
+chunks[10] = bytes(chunk)
+chunks[22] = np.random.default_rng(3).integers(0, 256, chunk, dtype=np.uint8).tobytes()
 p = lzma_amd.make_params(20, 64)
 from lzma_amd import _native as N
 st, outs = lzma_amd.encode_chunks(chunks, p)
@@ -170,7 +175,7 @@ assert (st == 0).all()
 assert N.last_timing()["coder_launches"] == 9, N.last_timing()
 st2, dec = lzma_amd.decode_batch(outs)
 assert (st2 == 0).all() and dec == chunks
-for i in (0, 4, 5, 17, 35):
+for i in (0, 4, 5, 9, 17, 22, 35):
     want = O.encode(chunks[i], O.params(dict_log=20, fb=64, lc=3, lp=0, pb=2, cut=1 << 30, eos=False))
     assert outs[i] == want, i
 print("batches ok")
