@@ -4,8 +4,9 @@
 // at every position of a stream.  Pipeline per batch of positions:
 //   1. key kernels: hash-2 / hash-3 / hash-4 slots (lz_bin_tree.go:139-143) and the first
 //      6 and 8 bytes of every position;
-//   2. stable radix sorts of (key, position) -- rocPRIM device radix sort, the one
-//      library primitive used -- giving each group's positions in ascending order.  The
+//   2. stable radix sorts of (key, position) -- rocPRIM's device radix sort when the finder
+//      has the device to itself, its own (rs_* kernels) beside resident encode launches --
+//      giving each group's positions in ascending order.  The
 //      16-gram table needs no sort over 16 bytes: the positions in 8-gram order, each
 //      moved back by 8, are already ordered by their bytes 8..15, and one stable sort by
 //      the 8-gram group of bytes 0..7 (a 31-bit key) finishes the order; the 32-, 64- and
@@ -179,14 +180,13 @@ unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 256 * 32) {
 }
 
 // Sort configurations.  The library's default for large inputs, the single-pass ("onesweep")
-// radix sort, is about three times faster than its merge-sort path here, but makes no progress
-// while an encode kernel of another stream is resident (measured: its first pass sits until the
-// first encode workgroup exits, about 5 s), which would serialize the finder/encoder pipeline:
-// its histogram kernel wants 32 KiB of LDS and its sort kernel 108 registers in each of the four
-// waves of a block, and twelve resident encode waves leave a CU 7 KiB and 56 registers per SIMD.
-// (A single-wave configuration that fits, 64 threads x 6 items x 6 bits, runs but is slower than
-// the merge path.)  The merge path runs next to the encoder unhindered.  So the default is used
-// when the finder has the device to itself (MfScratch::alone) and the merge path otherwise.
+// radix sort, is the fastest sort here when the finder has the device to itself
+// (MfScratch::alone), but it makes next to no progress while an encode kernel of another
+// stream is resident, even a single launch (its workgroups spin on the progress of other
+// workgroups), which would serialize the finder/encoder pipeline.  Its merge-sort path runs
+// next to the encoder unhindered but is three times slower.  Batches sorted beside encode
+// launches therefore use the finder's own radix sort further down (the merge path stays
+// selectable for comparison).
 using MergeCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                             rocprim::default_config, ~(size_t)0>;
 using AloneCfg = rocprim::default_config;
