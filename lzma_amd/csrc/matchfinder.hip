@@ -392,20 +392,28 @@ bool use_own_sort() {
     }();
     return own;
 }
+// LZMA_AMD_SORT=own: the finder's own sort also when it has the device to itself
+bool own_sort_always() {
+    static const bool v = [] {
+        const char *e = getenv("LZMA_AMD_SORT");
+        return e && strcmp(e, "own") == 0;
+    }();
+    return v;
+}
 
 // values out = the positions 0..n-1 ordered by key
 template <class K>
 int sort_by_key(lzh::MfScratch &s, K *keys_in, K *keys_out, uint32_t *vals_out, uint32_t n,
                 unsigned end_bit, hipStream_t st) {
     rocprim::counting_iterator<uint32_t> iota(0);
-    if (s.alone) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
+    if (s.alone && !own_sort_always()) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
     if (use_own_sort()) return own_sort_pairs<K>(s, keys_in, keys_out, nullptr, vals_out, n, end_bit, st);
     return sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, iota, vals_out, n, end_bit, st);
 }
 // values out = vals_in ordered by key (stable)
 int sort_vals_by_key(lzh::MfScratch &s, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in,
                      uint32_t *vals_out, uint32_t n, unsigned end_bit, hipStream_t st) {
-    if (s.alone) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
+    if (s.alone && !own_sort_always()) return sort_pairs_cfg<AloneCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
     if (use_own_sort()) return own_sort_pairs<uint32_t>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
     return sort_pairs_cfg<MergeCfg>(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, st);
 }

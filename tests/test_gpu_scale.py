@@ -184,3 +184,18 @@ print("batches ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "batches ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_finder_parity_with_its_own_sort_everywhere():
+    """The finder's own radix sort normally runs only beside resident encode launches; here the
+    whole match-finder parity suite runs with it in place of the library's sort (child process:
+    the choice is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LZMA_AMD_SORT="own")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_matchfinder.py",
+                        "tests/test_gpu_scale.py::test_match_lists_are_matches", "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
