@@ -146,10 +146,24 @@ def spawn_ranks(n):
     return rc
 
 
-def dist_init(backend):
+COLL_CPU = False  # collectives on CPU tensors (gloo) although the work runs on a GPU: --rehearse
+
+
+def dist_init(backend, rehearse=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rehearse:
+        # every rank on GPU 0, the ranks' exchange over gloo: the multi-rank path of the real
+        # workloads on a box with one GPU (RCCL refuses two ranks on one device)
+        global COLL_CPU
+        COLL_CPU = True
+        torch.cuda.set_device(0)
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        return rank, world, torch.device("cuda", 0)
     cuda = backend == "nccl"
     if cuda:
         torch.cuda.set_device(local if world > 1 else 0)
@@ -176,7 +190,7 @@ def reduce_ranks(x, world, dev, op):
     if world == 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if COLL_CPU else dev)
     dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
     return float(t.item())
 
@@ -224,7 +238,8 @@ class EncodeWorkload:
                                                  self.sizes.data_ptr(), self.status.data_ptr(), None))
             self.kernel_ms.append(N.last_timing())
         # container assembly: every rank learns every chunk's size -> global offsets
-        allsz = parallel.gather_sizes(self.sizes, self.total_chunks, self.rank, self.world)
+        allsz = parallel.gather_sizes(self.sizes.cpu() if COLL_CPU else self.sizes, self.total_chunks, self.rank,
+                                      self.world)
         self.offsets = parallel.container_offsets(allsz)
 
     def units(self):  # uncompressed bytes per step on this rank
@@ -633,6 +648,8 @@ def main():
     ap.add_argument("--mib", type=int, default=256, help="stream size in MiB (mf)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU rehearsal of the rank plumbing (stub workload only)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="all ranks on GPU 0 and their exchange over gloo: the multi-rank path on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -643,7 +660,7 @@ def main():
     if args.backend == "gloo" and args.workload != "stub":
         raise SystemExit("--backend gloo runs the stub workload only: the codec has no CPU path")
 
-    rank, world, dev = dist_init(args.backend)
+    rank, world, dev = dist_init(args.backend, args.rehearse)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if dev.type == "cuda":

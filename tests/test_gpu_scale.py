@@ -199,3 +199,20 @@ def test_finder_parity_with_its_own_sort_everywhere():
                         "tests/test_gpu_scale.py::test_match_lists_are_matches", "-x", "-q", "-m", "gpu",
                         "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 with both ranks on GPU 0 and their exchange over gloo: the ranks shard
+    the chunks, encode their shares with the real kernels, verify them through the GPU decoder
+    and agree on the container offsets."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rehearse", "--chunks", "65", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["chunks_total"] == 65 and line["config"]["chunks_this_rank"] == 33
