@@ -92,6 +92,14 @@ def pmc_lds(kernel, input_bytes_per_launch, kernel_ms):
         return None
 
 
+def pmc_traffic_mf(input_bytes_per_launch):
+    s = pmc_summary("pmc_mf_256MiB") or {}
+    try:
+        return int(s["kernels"]["mf_scan_kernel"]["hbm_bytes_per_input_byte_reported"] * input_bytes_per_launch)
+    except (KeyError, TypeError):
+        return None
+
+
 def pmc_traffic_decode(output_bytes_per_launch):
     s = pmc_summary("pmc_decode_125k_streams") or {}
     try:
@@ -538,7 +546,8 @@ class MfWorkload:
         gbs = alg / (avg_ms * 1e-3) / 1e9
         whole = alg / (sum(tot_ms) / len(tot_ms) * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "mf_scan_kernel", "achieved": round(gbs, 4),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 8), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 8),
+                "traffic": pmc_traffic_mf(self.n) if self.n == 256 * MIB else None,
                 "kernel_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": alg,
                 "total_ms_with_sorts": round(sum(tot_ms) / len(tot_ms), 3),
                 "achieved_with_sorts": round(whole, 4), "frac_with_sorts": round(whole / HBM_PEAK_GBS, 8)}

@@ -141,6 +141,10 @@ def main():
         timeline(run, prof, tag)
     if (run / "pmc" / "fetch.csv").exists():
         counters(run, prof, tag, chunks)
+    if (run / "pmc_mf" / "fetch.csv").exists():
+        counters(run, prof, tag, 256, sub="pmc_mf", name=f"{tag}_pmc_mf_256MiB.json",
+                 cmd="bench.py --workload mf --steps 1 --warmup 0 --no-cpu-baseline --no-verify",
+                 workload="match finder alone, one stream of 256 MiB, dict 1 MiB, fb 64, MI355X")
 
 
 def timeline(run, prof, tag):
@@ -161,12 +165,12 @@ def timeline(run, prof, tag):
                 f.write(f"    k  {b:9.1f} {e:9.1f} {e - b:8.1f} {short_name(nm)}\n")
 
 
-def counters(run, prof, tag, chunks):
+def counters(run, prof, tag, chunks, sub="pmc", name=None, cmd=None, workload=None):
     out = {}
     for d in ("fetch", "write", "sq", "l2"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls, seen = collections.Counter(), set()
-        for row in csv.DictReader(open(run / "pmc" / f"{d}.csv")):
+        for row in csv.DictReader(open(run / sub / f"{d}.csv")):
             k = kernel_class(row["Kernel_Name"])
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             if (k, row["Dispatch_Id"]) not in seen:
@@ -194,10 +198,10 @@ def counters(run, prof, tag, chunks):
                              "wave_cycles": round(4 * v["SQ_WAVE_CYCLES"] / n_in),
                              "wait_cycles": round(4 * v["SQ_WAIT_ANY"] / n_in)}}
     res = {
-        "command": f"rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --chunks {chunks} --steps 1 "
-                   "--warmup 0 --no-cpu-baseline --no-verify  (one run per counter group: FETCH_SIZE | WRITE_SIZE | "
-                   "SQ_* | TCC_HIT_sum TCC_MISS_sum)",
-        "workload": f"encode, {chunks} chunks of 1 MiB (one finder batch, one encode launch), MI355X",
+        "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 "
+                   + (cmd or f"bench.py --chunks {chunks} --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-extra")
+                   + "  (one run per counter group: FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_HIT_sum TCC_MISS_sum)",
+        "workload": workload or f"encode, {chunks} chunks of 1 MiB (one finder batch, one encode launch), MI355X",
         "input_bytes": n_in,
         "notes": ["FETCH_SIZE/WRITE_SIZE are in KB as rocprofv3 reports them, summed over the kernel's dispatches",
                   "FETCH_SIZE on gfx950 reports half of the bytes of 16-byte-per-lane streaming reads; the reads here "
@@ -207,7 +211,7 @@ def counters(run, prof, tag, chunks):
                   "LDS traffic of encode_kernel: SQ_INSTS_LDS wave instructions, most of them with one or a few "
                   "active lanes"],
         "kernels": rows}
-    (prof / f"{tag}_pmc_encode_{chunks}x1MiB.json").write_text(json.dumps(res, indent=1) + "\n")
+    (prof / (name or f"{tag}_pmc_encode_{chunks}x1MiB.json")).write_text(json.dumps(res, indent=1) + "\n")
     for k, v in rows.items():
         print(k, v["launches"], "B/byte", v["hbm_bytes_per_input_byte_reported"], "L2", v["l2_hit_rate"],
               v["per_position"], "fetchGB", round(v["FETCH_SIZE_KB"] * 1024 / 1e9, 1), "writeGB",
