@@ -122,3 +122,41 @@ def test_bad_params():
         with pytest.raises(N.NativeError) as ei:
             lzma_amd.encode_chunks([b"abc"], lzma_amd.make_params(**kw))
         assert ei.value.code == N.ERR_ARG
+
+
+def _mutated_repeats(n, block, seed):
+    r = np.random.default_rng(seed)
+    base = r.integers(97, 123, block, dtype=np.uint8)
+    out = np.tile(base, n // block + 1)[:n].copy()
+    hits = r.integers(0, n, max(1, n // 97))
+    out[hits] = r.integers(97, 123, hits.size, dtype=np.uint8)
+    return out
+
+
+def test_random_parameters():
+    """Forty draws of (data kind, length, dictionary, fast bytes, lc, lp, pb, end marker): bytes
+    equal to the oracle's at the exhaustive cut value, and both chunks of the call decode back."""
+    import lzma_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(2026)
+    for it in range(40):
+        n = int(rng.integers(1, 200000))
+        kind = it % 4
+        if kind == 0:
+            data = synth.markov(1 << 20)[:n]
+        elif kind == 1:
+            data = synth.logtext(1 << 20, block=1 << 20)[:n]
+        elif kind == 2:
+            data = _mutated_repeats(n, int(rng.integers(20, 500)), it)
+        else:
+            data = rng.integers(0, 256, n, dtype=np.uint8) if it % 8 == 3 else np.zeros(n, np.uint8)
+        data = bytes(np.asarray(data, dtype=np.uint8))
+        dict_log, fb = int(rng.integers(12, 27)), int(rng.choice([5, 8, 16, 32, 64, 128, 255, 256, 273]))
+        lc, lp, pb, eos = int(rng.integers(0, 5)), int(rng.integers(0, 3)), int(rng.integers(0, 5)), bool(it % 2)
+        what = (it, n, kind, dict_log, fb, lc, lp, pb, eos)
+        st, outs = lzma_amd.encode_chunks([data, data[: n // 3]], lzma_amd.make_params(dict_log, fb, lc, lp, pb, eos))
+        assert (st == 0).all(), what
+        want = O.encode(data, O.params(dict_log=dict_log, fb=fb, lc=lc, lp=lp, pb=pb, cut=1 << 30, eos=eos))
+        assert outs[0] == want, what
+        st2, dec = lzma_amd.decode_batch(outs)
+        assert (st2 == 0).all() and dec == [data, data[: n // 3]], what
