@@ -92,7 +92,7 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb) {
     l.pp = (l.prices + lz::price_layout(pb, fb).total * 2 + 15) & ~15u;
     l.opt = l.pp + 512 * 2;
     l.small = l.opt + (lz::kRecWin + lz::kBksWin) * 16;
-    l.total = l.small + lz::enc_small_words(fb) * 4;
+    l.total = l.small + lz::enc_small_words(fb, pb) * 4;
     return l;
 }
 

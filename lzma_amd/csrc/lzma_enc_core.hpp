@@ -54,11 +54,15 @@ constexpr uint32_t kRecBack = (kRecWin * 3) / 8;   // entries kept behind cur
 constexpr uint32_t kBksWin = kRecWin / 2;          // power of two
 // Sizes that follow from the number of fast bytes: a match list holds at most fb - 1
 // pairs (lengths 2..fb, strictly increasing), and lengths above fb are never priced.
-LZ_HD uint32_t la_max(uint32_t fb) { return 5 + fb + 1; }  // continuation records: literal, 4 reps, pairs
+LZ_HD uint32_t la_max(uint32_t fb) { return fb + 1; }  // continuation records of the pairs
 LZ_HD uint32_t mdist_words(uint32_t fb) { return 2 * (fb + 1) + 2; }
+// words shared by the continuation records (inside a parse) and the distance-price scratch (between parses)
+LZ_HD uint32_t la_words(uint32_t fb) { return 2 * la_max(fb) > kNumFullDist ? 2 * la_max(fb) : kNumFullDist; }
+// state-price table: one 16-byte entry per (state, posState)
+LZ_HD uint32_t sp_words(uint32_t pb) { return (kNumStates << pb) * 4; }
 // uint32 words of caller-provided scratch besides the tables (see Encoder::bind_small)
-LZ_HD uint32_t enc_small_words(uint32_t fb) {
-    return 32 + 2 * kPosStatesMax + kNumFullDist + 2 * la_max(fb) + mdist_words(fb);
+LZ_HD uint32_t enc_small_words(uint32_t fb, uint32_t pb) {
+    return sp_words(pb) + 4 + (2u << pb) + la_words(fb) + mdist_words(fb);
 }
 
 // LZ_LDS qualifies pointers into LDS, so that their accesses are ds_* instructions
@@ -259,12 +263,33 @@ struct Encoder {
         r.prp[3] = r.rep_match + g01 + g11 + g21;
         return r;
     }
-    // the same for a wave-uniform (state, posState), in scalar registers
+    // The models are frozen while a parse runs (they move when symbols are coded, between
+    // parses), so the state prices of all (state, posState) pairs are tabulated once per parse,
+    // one pair per lane, and a look-up is a single 16-byte read instead of six models and
+    // twelve bit prices.  Entry: {im0 | rep_match << 16, nmp | rep_len1 << 16, prp0 | prp1 << 16,
+    // prp2 | prp3 << 16}; every field is a sum of at most five bit prices and fits 16 bits.
+    LZ_HD void sp_refresh() {
+        const uint32_t total = kNumStates << ep.pb;
+        LZ_PAR_BEGIN(L)
+        for (uint32_t k = L; k < total; k += kLanes) {
+            const StatePrices v = sp_direct(k >> ep.pb, k & pos_state_mask);
+            Reps e;
+            e.r[0] = v.im0 | (v.rep_match << 16), e.r[1] = v.nmp | (v.rep_len1 << 16);
+            e.r[2] = v.prp[0] | (v.prp[1] << 16), e.r[3] = v.prp[2] | (v.prp[3] << 16);
+            sp_tab[k] = e;
+        }
+        LZ_PAR_END
+    }
+    // single fields, per lane
+    LZ_HD uint32_t sp_im0(uint32_t st, uint32_t ps) const { return sp_tab[(st << ep.pb) + ps].r[0] & 0xFFFF; }
+    LZ_HD uint32_t sp_prp0(uint32_t st, uint32_t ps) const { return sp_tab[(st << ep.pb) + ps].r[2] & 0xFFFF; }
+    // all fields of a wave-uniform (state, posState), in scalar registers
     LZ_HD StatePrices sp_get(uint32_t st, uint32_t ps) const {
-        const StatePrices v = sp_direct(st, ps);
+        const Reps v = sp_tab[(st << ep.pb) + ps];
+        const Reps e = ureps(v);
         StatePrices r;
-        r.im0 = U(v.im0), r.rep_match = U(v.rep_match), r.nmp = U(v.nmp), r.rep_len1 = U(v.rep_len1);
-        r.prp[0] = U(v.prp[0]), r.prp[1] = U(v.prp[1]), r.prp[2] = U(v.prp[2]), r.prp[3] = U(v.prp[3]);
+        r.im0 = e.r[0] & 0xFFFF, r.rep_match = e.r[0] >> 16, r.nmp = e.r[1] & 0xFFFF, r.rep_len1 = e.r[1] >> 16;
+        r.prp[0] = e.r[2] & 0xFFFF, r.prp[1] = e.r[2] >> 16, r.prp[2] = e.r[3] & 0xFFFF, r.prp[3] = e.r[3] >> 16;
         return r;
     }
 
@@ -278,24 +303,21 @@ struct Encoder {
     uint32_t align_price_count, match_price_count, pos_state_mask, lit_pos_mask;
     uint32_t now_pos, finished, state, prev_byte, back_res;
     // Small arrays in caller-provided (LDS) memory: never in per-lane scratch.
-    U32P rep_dist, reps, rep_lens, rep_prp;          // 4 each
-    U32P xch;                                        // 16 words exchanged between phases
-    U32P len_counter;                                // [2][kPosStatesMax]
-    U32P temp_prices;                                // kNumFullDist
-    U32P la_tgt, la_price;                           // la_max(fb) each: target entry (0 = none), price
+    LZ_LDS Reps *sp_tab;                             // state prices of every (state, posState), see sp_refresh
+    U32P rep_dist;                                   // 4
+    U32P len_counter;                                // [2][1 << pb]
+    U32P temp_prices;                                // kNumFullDist; shares its words with la_tgt / la_price
+    U32P la_tgt, la_price;                           // la_max(fb) each, by pair: target entry (0 = none), price
     U32P mdist;                                      // current match list, (len, dist) pairs
 
-    LZ_HD void bind_small(U32P small, uint32_t fb) {
-        rep_dist = small;
-        reps = small + 4;
-        rep_lens = small + 8;
-        rep_prp = small + 12;
-        xch = small + 16;
-        len_counter = small + 32;
-        temp_prices = len_counter + 2 * kPosStatesMax;
-        la_tgt = temp_prices + kNumFullDist;
+    LZ_HD void bind_small(U32P small, uint32_t fb, uint32_t pb) {
+        sp_tab = (LZ_LDS Reps *)small;               // 16-byte aligned: first
+        rep_dist = small + sp_words(pb);
+        len_counter = rep_dist + 4;
+        temp_prices = len_counter + (2u << pb);
+        la_tgt = temp_prices;
         la_price = la_tgt + la_max(fb);
-        mdist = la_price + la_max(fb);
+        mdist = temp_prices + la_words(fb);
     }
 
     // ------------------------------------------------------- optimum table access
@@ -513,7 +535,7 @@ struct Encoder {
             pr[i] = (WT)v;
         }
         LZ_PAR_END
-        if (one()) len_counter[which * kPosStatesMax + ps] = nsym;
+        if (one()) len_counter[(which << ep.pb) + ps] = nsym;
     }
     LZ_HD void len_encode(uint32_t which, uint32_t sym, uint32_t ps) {  // :48-63, :120-126
         const uint32_t b = len_base(which);
@@ -531,8 +553,8 @@ struct Encoder {
                 bt_encode(probs, b + LEN_HIGH, 8, s - kLenMid);
             }
         }
-        const uint32_t left_ = U(len_counter[which * kPosStatesMax + ps]) - 1;
-        if (one()) len_counter[which * kPosStatesMax + ps] = left_;
+        const uint32_t left_ = U(len_counter[(which << ep.pb) + ps]) - 1;
+        if (one()) len_counter[(which << ep.pb) + ps] = left_;
         if (left_ == 0) len_set_prices(which, ps);
     }
     LZ_HD uint32_t len_price(uint32_t which, uint32_t sym, uint32_t ps) const {
@@ -747,8 +769,8 @@ struct Encoder {
             }
             if (with_la)
                 for (uint32_t j = A.first_la; j < A.npairs; j++)
-                    if (la_tgt[5 + j] == x && la_price[5 + j] < price) {
-                        price = la_price[5 + j], back = 0, back2 = mdist[2 * j + 1] + kNumReps;
+                    if (la_tgt[j] == x && la_price[j] < price) {
+                        price = la_price[j], back = 0, back2 = mdist[2 * j + 1] + kNumReps;
                         ppw = (cur + mdist[2 * j] + 1) | (cur << 12) | kPpPrev1 | kPpPrev2;
                         is_la = true, changed = true;
                     }
@@ -949,6 +971,7 @@ struct Encoder {
         uint32_t ps = position & pos_state_mask;
         uint32_t rep_len1;
         uint32_t rep_match_price, nmp;
+        sp_refresh();
         {
             const StatePrices sp0 = sp_get(state, ps);
             const uint32_t im0 = sp0.im0;
@@ -1192,12 +1215,10 @@ struct Encoder {
                         const uint32_t s_after = is_rep ? st_rep(st) : st_match(st);
                         const uint32_t s2s = st_char(s_after);
                         const uint32_t psn = pos_after & pos_state_mask, psn2 = (pos_after + 1) & pos_state_mask;
-                        // models first, then prices: two batches of loads
-                        const uint32_t m_a = probs[P_IS_MATCH + LZ_IDX(s_after, psn)];
-                        const uint32_t m_b = probs[P_IS_MATCH + LZ_IDX(s2s, psn2)], m_c = probs[P_IS_REP + s2s];
-                        const uint32_t m_d = probs[P_IS_REP_G0 + s2s], m_e = probs[P_IS_REP0_LONG + LZ_IDX(s2s, psn2)];
-                        const uint32_t g_im0 = price0(m_a);
-                        const uint32_t g_tail = price1(m_b) + price1(m_c) + price0(m_d) + price1(m_e);
+                        // the literal is a non-match in the state after the step, the rep0 after it a
+                        // "match, rep, rep0 of more than one byte" in the state after the literal
+                        const uint32_t g_im0 = sp_im0(s_after, psn);
+                        const uint32_t g_tail = sp_prp0(s2s, psn2);
                         const uint32_t base = is_rep ? rprp + len_price(1, lt - kMatchMin, ps)
                                                      : nmp + pos_len_price(dist, lt, ps);
                         la_p = base + g_im0 + litp + g_tail + len_price(1, s2 - kMatchMin, psn2);
@@ -1211,8 +1232,8 @@ struct Encoder {
                 if (is_rep) {
                     LZ_LV(x0, L) = s1, LZ_LV(x1, L) = tgt, LZ_LV(x2, L) = la_p;
                 } else if (!is_lit && do_rest && L >= 8 && j < npairs) {
-                    la_tgt[5 + j] = tgt;
-                    la_price[5 + j] = la_p;
+                    la_tgt[j] = tgt;
+                    la_price[j] = la_p;
                     if (first) LZ_LV(x0, L) = lt_pair, LZ_LV(x1, L) = tgt, LZ_LV(x2, L) = la_p;
                 }
             }
@@ -1258,7 +1279,7 @@ struct Encoder {
                     // "match, rep, rep0 of more than one byte" after the literal: the rep0 price of
                     // (state after the literal, its posState) plus the length
                     const uint32_t lenp_v = len_price(1, l2 - kMatchMin, psn);
-                    const uint32_t tail = sp_get(s2, psn).prp[0] + U(lenp_v);
+                    const uint32_t tail = U(sp_prp0(s2, psn)) + U(lenp_v);
                     A.lt[0] = cur + 1 + l2;
                     A.lp[0] = cur_and1 + tail;
                     if (cur + 1 + l2 > new_end) new_end = cur + 1 + l2;
@@ -1298,7 +1319,7 @@ struct Encoder {
                     if (first_la == in_lanes)
                         while (U(mdist[2 * first_la]) < start_len) first_la++;
                     for (uint32_t j = first_la > in_lanes ? first_la : in_lanes; j < npairs; j++) {
-                        const uint32_t tg = U(la_tgt[5 + j]);
+                        const uint32_t tg = U(la_tgt[j]);
                         if (tg > new_end) new_end = tg;
                     }
                 }
@@ -1474,7 +1495,7 @@ struct Encoder {
     // Models must already hold kProbInit and pp must be built.  Encodes the whole
     // chunk; out_n receives the payload size (header excluded).
     LZ_HD void run(U32P small) {
-        bind_small(small, ep.fb);
+        bind_small(small, ep.fb, ep.pb);
         low = 0;
         out_n = 0;
         cache_size = 1;
@@ -1488,7 +1509,7 @@ struct Encoder {
         state = 0;
         prev_byte = 0;
         back_res = 0;
-        for (int i = 0; i < 4; i++) rep_dist[i] = rep_lens[i] = 0;
+        for (int i = 0; i < 4; i++) rep_dist[i] = 0;
         pos_state_mask = (1u << ep.pb) - 1;
         lit_pos_mask = (1u << ep.lp) - 1;
         pl = price_layout(ep.pb, ep.fb);

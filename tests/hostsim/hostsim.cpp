@@ -102,7 +102,7 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     std::vector<lz::OptG> opt_g(lz::kNumOpts);
     std::vector<lz::Rec> opt_rec(lz::kRecWin);
     std::vector<lz::Reps> opt_bks(lz::kBksWin);
-    std::vector<uint32_t> small(lz::enc_small_words(fb));
+    std::vector<uint32_t> small(lz::enc_small_words(fb, pb));
     lz::build_prob_prices(pp.data(), 0, 1);
     lz::Encoder<ChainMFRef, lz::prob_t *> e;
     e.data = padded.data();
