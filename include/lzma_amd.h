@@ -173,6 +173,8 @@ int lzma_amd_parse_header(const uint8_t *in, size_t n, uint32_t *lc, uint32_t *l
 void lzma_amd_last_timing(float *ms_total, float *ms_finder, float *ms_coder);
 /* Number of coder kernel launches ms_coder sums over (0 for the finder). */
 int lzma_amd_last_coder_launches(void);
+/* How many of them ran two waves per chunk (encoder only; see lzma_amd_encode_chunks_dev). */
+int lzma_amd_last_coop_launches(void);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "lzma_amd_last_error", "lzma_amd_version", "lzma_amd_encode_bound", "lzma_amd_bt4_matches",
     "lzma_amd_bt4_matches_dev", "lzma_amd_encode_chunks", "lzma_amd_encode_chunks_dev",
     "lzma_amd_decode_batch", "lzma_amd_decode_batch_dev", "lzma_amd_parse_header",
-    "lzma_amd_last_timing", "lzma_amd_last_coder_launches", "lzma_amd_release_workspace",
+    "lzma_amd_last_timing", "lzma_amd_last_coder_launches", "lzma_amd_last_coop_launches", "lzma_amd_release_workspace",
     "lzma_amd_decode_batch_dev_noalloc",
 ]
 
@@ -71,6 +71,7 @@ def lib():
     L.lzma_amd_parse_header.argtypes = [vp, sz] + [C.POINTER(C.c_uint32)] * 4 + [C.POINTER(C.c_int64)]
     L.lzma_amd_last_timing.argtypes = [C.POINTER(C.c_float)] * 3
     L.lzma_amd_last_coder_launches.restype = C.c_int
+    L.lzma_amd_last_coop_launches.restype = C.c_int
     _lib = L
     return L
 
@@ -89,4 +90,5 @@ def last_timing():
     a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
     lib().lzma_amd_last_timing(C.byref(a), C.byref(b), C.byref(c))
     return {"total_ms": a.value, "finder_ms": b.value, "coder_ms": c.value,
-            "coder_launches": int(lib().lzma_amd_last_coder_launches())}
+            "coder_launches": int(lib().lzma_amd_last_coder_launches()),
+            "coop_launches": int(lib().lzma_amd_last_coop_launches())}

@@ -74,5 +74,6 @@ void lzma_amd_last_timing(float *ms_total, float *ms_finder, float *ms_coder) {
 }
 
 int lzma_amd_last_coder_launches(void) { return lzh::tls().coder_launches; }
+int lzma_amd_last_coop_launches(void) { return lzh::tls().coop_launches; }
 
 }  // extern "C"

@@ -33,7 +33,8 @@ namespace {
 // for consecutive positions almost all the time, so the words of the next position's
 // list (one per lane) and the result word of the position after it are requested
 // one call ahead and are usually there when needed.
-template <bool PACKED>
+// STEP: distance between the positions one wave asks for (2 when two waves share a chunk).
+template <bool PACKED, uint32_t STEP = 1>
 struct MfFunctor {
     static __device__ uint64_t uni64(uint64_t v) {
         return ((uint64_t)lz::U((uint32_t)(v >> 32)) << 32) | lz::U((uint32_t)v);
@@ -66,7 +67,7 @@ struct MfFunctor {
             const uint32_t *src = arena + first(m);
             for (uint32_t k = lane; k < words(c); k += 64) put(out, k, src[k]);
         }
-        uint32_t g1 = job_start + pos + 1, g2 = job_start + pos + 2;
+        uint32_t g1 = job_start + pos + STEP, g2 = job_start + pos + 2 * STEP;
         if (g1 >= n_total) g1 = n_total - 1;
         if (g2 >= n_total) g2 = n_total - 1;
         const uint64_t m1 = uni64(hit ? pf_meta2 : meta[g1]);
@@ -76,15 +77,16 @@ struct MfFunctor {
         pf_word = w;
         pf_meta = m1;
         pf_meta2 = meta[g2];
-        pf_pos = pos + 1;
+        pf_pos = pos + STEP;
         return c;
     }
 };
 
 struct LdsLayout {
     uint32_t probs, prices, pp, opt, small, total;  // byte offsets
+    uint32_t sync, own1;                            // cooperative workgroups only
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb) {
+__host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb, bool coop) {
     LdsLayout l;
     uint32_t nprobs = lz::kNumBaseProbs;
     l.probs = 0;
@@ -93,13 +95,21 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb) {
     l.opt = l.pp + 512 * 2;
     l.small = l.opt + (lz::kRecWin + lz::kBksWin) * 16;
     l.total = l.small + lz::enc_small_words(fb, pb) * 4;
+    l.sync = l.own1 = l.total;
+    if (coop) {  // the block the two waves synchronise through, and the second wave's match list and records
+        l.own1 = l.sync + lz::SY_WORDS * 4;
+        l.total = l.own1 + (lz::la_words(fb) + lz::mdist_words(fb)) * 4;
+    }
     return l;
 }
 
 // Chunks [c0, c0 + nchunks) of the call; their bytes start at data offset
 // in_off[c] - base inside t.data.
-template <bool PACKED>
-__global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
+// COOP: two waves per chunk (workgroups of 128 threads), for launches that leave wave slots
+// free: the parse loop of a chunk runs on both (lz::Encoder::parse_loop), everything else on
+// the first.
+template <bool PACKED, bool COOP>
+__global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
                                                     const uint64_t *__restrict__ mf_meta,
                                                     const uint32_t *__restrict__ mf_arena,
                                                     const uint64_t *__restrict__ in_off,
@@ -113,35 +123,39 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
     // A chunk's wave is one long dependent chain; the finder's waves sharing its SIMD are many
     // and interchangeable.  Issue priority to the chain: the finder fills the slots it leaves.
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = threadIdx.x;
-    const LdsLayout L = lds_layout(ep.pb, ep.fb);
+    constexpr uint32_t kThreads = COOP ? 128 : 64;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = COOP ? lz::U(threadIdx.x >> 6) : 0;
+    const LdsLayout L = lds_layout(ep.pb, ep.fb, COOP);
     LZ_LDS uint8_t *sm = (LZ_LDS uint8_t *)smem;
     LZ_LDS lz::prob_t *probs = (LZ_LDS lz::prob_t *)(sm + L.probs);
     LZ_LDS uint16_t *prices = (LZ_LDS uint16_t *)(sm + L.prices);
     LZ_LDS uint16_t *pp = (LZ_LDS uint16_t *)(sm + L.pp);
     LZ_LDS uint32_t *optl = (LZ_LDS uint32_t *)(sm + L.opt);
     LZ_LDS uint32_t *small = (LZ_LDS uint32_t *)(sm + L.small);
+    LZ_LDS uint32_t *sync = (LZ_LDS uint32_t *)(sm + L.sync);
     const uint32_t lit_n = 0x300u << (ep.lc + ep.lp);
-    lz::build_prob_prices((uint16_t *)pp, lane, 64u);
+    lz::build_prob_prices((uint16_t *)pp, threadIdx.x, kThreads);
 
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint64_t chunk = c0 + c;
         const uint32_t jb = (uint32_t)(in_off[chunk] - base), je = (uint32_t)(in_off[chunk + 1] - base);
         const uint64_t ob = out_off[chunk], oe = out_off[chunk + 1];
         if (oe - ob < lz::kHeaderSize) {
-            if (lane == 0) {
+            if (threadIdx.x == 0) {
                 status[chunk] = lz::ST_OUT_CAP;
                 out_sizes[chunk] = 0;
             }
             continue;
         }
         __syncthreads();
-        for (uint32_t i = lane; i < lz::kNumBaseProbs; i += 64) probs[i] = lz::kProbInit;
+        for (uint32_t i = threadIdx.x; i < lz::kNumBaseProbs; i += kThreads) probs[i] = lz::kProbInit;
         lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_stride;
-        for (uint32_t i = lane; i < lit_n; i += 64) lit[i] = lz::kProbInit;
+        for (uint32_t i = threadIdx.x; i < lit_n; i += kThreads) lit[i] = lz::kProbInit;
+        if (COOP && threadIdx.x < lz::SY_WORDS) sync[threadIdx.x] = 0;
         __syncthreads();
 
-        lz::Encoder<MfFunctor<PACKED>, lz::prob_t *> e;
+        lz::Encoder<MfFunctor<PACKED, COOP ? 2 : 1>, lz::prob_t *, COOP> e;
         e.data = data + jb;
         e.n = je - jb;
         e.readable = data_n - jb;
@@ -151,16 +165,21 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
         e.pp = pp;
         e.o_rec = (LZ_LDS lz::Rec *)optl;
         e.o_bks = (LZ_LDS lz::Reps *)(optl + 4 * lz::kRecWin);
+        e.sync = sync;
         e.opt_g = opt_scratch + (uint64_t)blockIdx.x * lz::kNumOpts;
         e.lane_id = lane;
         e.out = out + ob + lz::kHeaderSize;
         e.out_cap = oe - ob - lz::kHeaderSize;
-        e.mf = MfFunctor<PACKED>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
+        e.mf = MfFunctor<PACKED, COOP ? 2 : 1>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
         e.ep = ep;
 #if defined(LZ_PROFILE)
         for (int i = 0; i < 12; i++) e.prof[i] = 0;
         e.prof_last = __builtin_readcyclecounter();
 #endif
+        if (COOP && wave != 0) {
+            e.helper_run(small, (LZ_LDS uint32_t *)(sm + L.own1));
+            continue;
+        }
         e.run(small);
 #if defined(LZ_PROFILE)
         if (lane == 0 && blockIdx.x == 0)
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(64) void encode_kernel(const uint8_t *__restrict__ 
 #endif
         if (lane == 0) {
             lz::write_header(out + ob, ep, ep.eos ? -1 : (int64_t)e.n);
-            status[chunk] = e.overflow ? lz::ST_OUT_CAP : lz::ST_OK;
+            status[chunk] = e.dead ? lz::ST_HIP : (e.overflow ? lz::ST_OUT_CAP : lz::ST_OK);
             out_sizes[chunk] = lz::kHeaderSize + e.out_n;
         }
     }
@@ -282,12 +301,12 @@ struct Workspace {
 // never destroyed on its own: at process exit the HIP runtime may already be gone
 thread_local Workspace *g_ws = nullptr;
 
-template <bool PACKED>
+template <bool PACKED, bool COOP>
 int launch_encode(unsigned grid, unsigned lds, hipStream_t es, const uint8_t *data, uint32_t nbytes,
                   const lzh::MfResult &res, const uint64_t *d_in_off, uint64_t base, uint64_t c0, uint32_t nchunks,
                   const lz::EncParams &ep, uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
                   int32_t *d_status, lz::OptG *opt, lz::prob_t *lit, uint64_t lit_stride) {
-    hipLaunchKernelGGL(encode_kernel<PACKED>, dim3(grid), dim3(64), lds, es, data, nbytes, res.d_meta(),
+    hipLaunchKernelGGL((encode_kernel<PACKED, COOP>), dim3(grid), dim3(COOP ? 128 : 64), lds, es, data, nbytes, res.d_meta(),
                        res.d_arena(), d_in_off, base, c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
                        opt, lit, lit_stride);
     LZ_HIP(hipGetLastError());
@@ -307,7 +326,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     hipStream_t st = (hipStream_t)stream;
     lzh::ThreadState &ts = lzh::tls();
     ts.ms_total = ts.ms_finder = ts.ms_coder = 0.f;
-    ts.coder_launches = 0;
+    ts.coder_launches = ts.coop_launches = 0;
     int rc = check_params(p);
     if (rc) return rc;
     if (n_chunks == 0) return LZMA_AMD_OK;
@@ -328,7 +347,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
                          (unsigned long long)off[n_chunks], in_total);
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
-    const LdsLayout L = lds_layout(p->pb, p->fb);
+    const LdsLayout L = lds_layout(p->pb, p->fb, false), LC = lds_layout(p->pb, p->fb, true);
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
     const bool packed = lz::mf_can_pack(ep.dict_size);
 
@@ -349,8 +368,8 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     unsigned per_cu = std::min(kWavesPerSimd * S.shape.simds_per_cu, S.shape.lds_per_cu / lds_per_wg);
     {
         int api = 0;
-        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true>, 64, L.total)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false>, 64, L.total);
+        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, false>, 64, L.total)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, false>, 64, L.total);
         if (e == hipSuccess && api > 0) per_cu = std::min(per_cu, (unsigned)api);
     }
     unsigned resident = S.shape.cus * std::max(1u, per_cu);
@@ -478,6 +497,8 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     std::vector<Held> held;
     int co_run = 1;
     if (const char *e = getenv("LZMA_AMD_CO_RUN")) co_run = std::max(0, atoi(e));
+    int coop_mode = -1;  // -1: by the number of chunks left, 0: never, 1: always
+    if (const char *e = getenv("LZMA_AMD_COOP")) coop_mode = atoi(e);
     auto running = [&]() -> int {
         int n = 0;
         for (int i = 0; i < nslots; i++)
@@ -489,12 +510,15 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         hipStream_t es = S.enc[h.b % in_flight];
         const unsigned grid = std::min(h.nchunks, grid_cap);
         LZ_HIP_BAIL(hipEventRecord(sl.e0, es));
-        int r = packed ? launch_encode<true>(grid, L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,
-                                             (uint64_t)cut[h.b], h.nchunks, ep, d_out, d_out_off, d_out_sizes,
-                                             d_status, sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride)
-                       : launch_encode<false>(grid, L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,
-                                              (uint64_t)cut[h.b], h.nchunks, ep, d_out, d_out_off, d_out_sizes,
-                                              d_status, sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride);
+        // Two waves per chunk when the chunks still to be encoded leave wave slots free: the
+        // call's last launches, and calls with few chunks altogether.
+        const bool coop = coop_mode == 1 || (coop_mode < 0 && 2 * (uint64_t)(n_chunks - cut[h.b]) <= resident);
+        auto fn = packed ? (coop ? launch_encode<true, true> : launch_encode<true, false>)
+                         : (coop ? launch_encode<false, true> : launch_encode<false, false>);
+        int r = fn(grid, coop ? LC.total : L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,
+                   (uint64_t)cut[h.b], h.nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
+                   sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride);
+        if (coop) ts.coop_launches++;
         if (r) return bail(r);
         LZ_HIP_BAIL(hipEventRecord(sl.e1, es));
         sl.busy = true;

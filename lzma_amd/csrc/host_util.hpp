@@ -14,7 +14,7 @@ namespace lzh {
 struct ThreadState {
     char err[512];
     float ms_total, ms_finder, ms_coder;
-    int coder_launches;
+    int coder_launches, coop_launches;
 };
 ThreadState &tls();
 int fail(int code, const char *fmt, ...);

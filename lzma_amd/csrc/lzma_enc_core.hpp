@@ -214,7 +214,49 @@ LZ_HD uint64_t enc_load8(const uint8_t *p) {
     return v;
 }
 
-template <class MF, class LP>
+// Words of the block through which the two waves of a cooperative workgroup synchronise
+// (see Encoder::parse_loop).  Counters grow with the parse position inside one parse.
+enum : uint32_t {
+    SY_FORK = 0,   // parses started (written by wave 0); kSyDone: the chunk is finished
+    SY_JOIN,       // parses the second wave has left
+    SY_S,          // highest position whose round is done and whose literal candidate is published
+    SY_A,          // highest position whose apply phase is done; SY_LEN_END / SY_FAR_HI belong to it
+    SY_M,          // highest position whose literal candidate has been merged into the next entry
+    SY_EXIT,       // a wave has found the end of the parse: SY_EX_* are valid
+    SY_LEN_END, SY_FAR_HI,
+    SY_PKT_PRICE, SY_PKT_SP = SY_PKT_PRICE + 2, SY_PKT_EQ = SY_PKT_SP + 2,  // literal candidate, by parity
+    SY_NIC = SY_PKT_EQ + 2,                                                  // its outcome, by parity
+    SY_EX_CUR = SY_NIC + 2, SY_EX_LONG, SY_EX_LEN, SY_EX_DIST,
+    SY_POS0, SY_MF0,
+    SY_WORDS = 32
+};
+constexpr uint32_t kSyDone = 0xFFFFFFFFu;
+
+// Flag accesses between the waves of a workgroup.  Data written before lz_sy_store is visible
+// to a wave that has seen the stored value with lz_sy_load.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+LZ_D uint32_t lz_sy_load(const LZ_LDS uint32_t *p) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const volatile LZ_LDS uint32_t *)p);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+LZ_D void lz_sy_store(LZ_LDS uint32_t *p, uint32_t v, bool one_lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (one_lane) *(volatile LZ_LDS uint32_t *)p = v;
+}
+LZ_D void lz_sy_pause() { __builtin_amdgcn_s_sleep(1); }
+#else
+}  // namespace lz
+#include <sched.h>
+namespace lz {
+inline uint32_t lz_sy_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void lz_sy_store(uint32_t *p, uint32_t v, bool) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline void lz_sy_pause() { sched_yield(); }
+#endif
+
+// COOP: two waves share one chunk (parse_loop); each wave has an Encoder of its own over the
+// same LDS and HBM state, with a match-list buffer and continuation records of its own.
+template <class MF, class LP, bool COOP = false>
 struct Encoder {
     typedef LZ_LDS prob_t *PP;
     typedef LZ_LDS uint32_t *U32P;
@@ -230,6 +272,7 @@ struct Encoder {
     LZ_LDS Rec *o_rec;    // kRecWin slots: price, backPrev, packed path word, backPrev2
     LZ_LDS Reps *o_bks;   // kBksWin slots: backs0..3
     uint32_t wlo, wcur, far_hi;  // window start, current cur, highest entry written outside the window
+    U32P sync;                   // COOP: SY_WORDS words shared by the two waves
     OptG *opt_g;          // kNumOpts entries (HBM), always current
     uint8_t *out;         // payload output (after the header)
     uint64_t out_cap;
@@ -326,7 +369,10 @@ struct Encoder {
     // Stores from wave-uniform code are issued by one lane: 64 lanes writing the same
     // address cost the memory pipeline 64 writes.
     LZ_HD bool one() const { return lane_id == 0; }
-    LZ_HD bool in_win(uint32_t i) const { return i - wlo < kRecWin; }
+    // two waves at consecutive positions see windows one entry apart in the same ring: their
+    // union must fit it, so a cooperative window is one entry shorter
+    static constexpr uint32_t kWinSpan = COOP ? kRecWin - 1 : kRecWin;
+    LZ_HD bool in_win(uint32_t i) const { return i - wlo < kWinSpan; }
     LZ_HD bool in_bwin(uint32_t i) const { return wcur - i < kBksWin; }
     LZ_HD Rec grec(uint32_t i) const {
         Rec r;
@@ -404,13 +450,65 @@ struct Encoder {
         const uint32_t lo = c > kRecBack ? c - kRecBack : 0;
         if (lo != wlo) {
             wlo = lo;
-            const uint32_t e = lo + kRecWin - 1;
+            const uint32_t e = lo + kWinSpan - 1;
+            if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
+        }
+    }
+    // COOP: the window of position c is set when the wave turns to c (win_set) and the entry it
+    // gains is fetched when the apply phases of all earlier positions are done (win_enter)
+    LZ_HD void win_set(uint32_t c) {
+        wcur = c;
+        wlo = c > kRecBack ? c - kRecBack : 0;
+    }
+    LZ_HD void win_enter(uint32_t c) {
+        if (c > kRecBack) {
+            const uint32_t e = c - kRecBack + kWinSpan - 1;
             if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
         }
     }
     LZ_HD void note_far(uint32_t hi) {  // an apply phase wrote entries up to hi
-        if (hi >= wlo + kRecWin && hi > far_hi) far_hi = hi;
+        if (hi >= wlo + kWinSpan && hi > far_hi) far_hi = hi;
     }
+    // ---- the two waves of a cooperative workgroup
+    // Every wait between the waves is bounded (about a second; the longest legitimate wait, for
+    // the symbols of one parse to be coded, is a thousand times shorter): a wave that gives up
+    // raises kSyAbort in SY_EXIT, which ends every other wait, and the chunk reports an error.
+    static constexpr uint32_t kSpinLimit = 1u << 23;
+    static constexpr uint32_t kSyAbort = 2;
+    uint32_t dead;  // this wave gave up, or saw the other one do so
+    LZ_HD void sy_give_up() {
+        dead = 1;
+        lz_sy_store(sync + SY_EXIT, kSyAbort, one());
+    }
+    // waits until counter `which` has reached v; false if the parse has ended meanwhile
+    LZ_HD bool sy_wait(uint32_t which, uint32_t v) {
+        for (uint32_t spins = 0;; spins++) {
+            if (lz_sy_load(sync + which) >= v) return true;
+            const uint32_t x = lz_sy_load(sync + SY_EXIT);
+            if (x != 0) {
+                if (x == kSyAbort) dead = 1;
+                return false;
+            }
+            if (spins > kSpinLimit) {
+                sy_give_up();
+                return false;
+            }
+            lz_sy_pause();
+        }
+    }
+    // waits until word `which` differs from (differ) or equals (!differ) v; 0 after giving up
+    LZ_HD uint32_t sy_wait_word(uint32_t which, uint32_t v, bool differ) {
+        for (uint32_t spins = 0;; spins++) {
+            const uint32_t f = lz_sy_load(sync + which);
+            if ((f != v) == differ) return f;
+            if (lz_sy_load(sync + SY_EXIT) == kSyAbort || spins > (differ ? kSpinLimit << 4 : kSpinLimit)) {
+                sy_give_up();
+                return 0;
+            }
+            lz_sy_pause();
+        }
+    }
+    LZ_HD void sy_signal(uint32_t which, uint32_t v) { lz_sy_store(sync + which, v, one()); }
 
     // ------------------------------------------------------------ range coder
     LZ_HD void rc_put(uint32_t b) {
@@ -934,8 +1032,6 @@ struct Encoder {
         // hand their results over in x0 / x1
         LZ_LANEVAR(x0);
         LZ_LANEVAR(x1);
-        LZ_LANEVAR(x2);
-        LZ_LANEVAR(x3);
         LZ_PAR_BEGIN(L)
         if (L < kNumReps) {
             LZ_LV(x0, L) = match_len(-1, rep_dist[L], kMatchMax);
@@ -1017,25 +1113,185 @@ struct Encoder {
             note_far(len_end);
         }
 
-        uint32_t cur = 0;
+        LoopExit ex;
+        if constexpr (COOP) {
+            // hand the loop to both waves: this one takes the odd positions
+            const uint32_t mf0 = mfpos, add0 = add_offset;
+            if (one()) {
+                sync[SY_S] = 0, sync[SY_A] = 0, sync[SY_M] = 0, sync[SY_EXIT] = 0;
+                sync[SY_LEN_END] = len_end, sync[SY_FAR_HI] = far_hi;
+                sync[SY_POS0] = position, sync[SY_MF0] = mf0;
+            }
+            const uint32_t seq = lz_sy_load(sync + SY_FORK) + 1;
+            sy_signal(SY_FORK, seq);
+            const bool mine = parse_loop(1, position, mf0, len_end, ex);
+            (void)sy_wait_word(SY_JOIN, seq, false);
+            if (dead) {  // the waves lost each other: end the chunk, which reports the error
+                back_res = 0xFFFFFFFFu;
+                return 1;
+            }
+            if (!mine) {
+                const uint32_t c_v = sync[SY_EX_CUR], l_v = sync[SY_EX_LONG], n_v = sync[SY_EX_LEN], d_v = sync[SY_EX_DIST];
+                ex.cur = U(c_v), ex.long_match = U(l_v), ex.longest_len = U(n_v), ex.last_dist = U(d_v);
+            }
+            // the match finder has been asked for the positions up to the last one parsed
+            const uint32_t reads = ex.long_match ? ex.cur : ex.cur - 1;
+            mfpos = mf0 + reads, add_offset = add0 + reads;
+            if (ex.long_match) {  // the next parse starts from this match
+                longest_len = ex.longest_len, longest_found = 1;
+                dist_pairs = 2;
+                if (one()) mdist[0] = ex.longest_len, mdist[1] = ex.last_dist;
+            }
+        } else {
+            parse_loop(1, position, mfpos, len_end, ex);
+        }
+        commit_from_window(ex.cur);
+        return backward(ex.cur);
+    }
+
+    // How the main loop of a parse ended: at the end of the parse range (cur == lenEnd, :509-511)
+    // or at a position whose longest match has at least fb bytes (:517-522).
+    struct LoopExit {
+        uint32_t cur, long_match, longest_len, last_dist;
+    };
+    // second wave of a cooperative workgroup: takes part in every parse loop wave 0 starts,
+    // until wave 0 reports the chunk finished
+    LZ_HD void helper_run(U32P small, U32P own) {
+        bind_small(small, ep.fb, ep.pb);
+        la_tgt = own, la_price = own + la_max(ep.fb), mdist = own + la_words(ep.fb);
+        pos_state_mask = (1u << ep.pb) - 1;
+        lit_pos_mask = (1u << ep.lp) - 1;
+        pl = price_layout(ep.pb, ep.fb);
+        uint32_t seq = 0;
+        dead = 0;
         for (;;) {
-            cur++;
-            if (cur == len_end) {
-                commit_from_window(cur);
-                return backward(cur);
+            // (wave 0 codes the symbols of a parse between two loops: this wait is the long one)
+            const uint32_t f = sy_wait_word(SY_FORK, seq, true);
+            if (dead || f == kSyDone) return;
+            seq = f;
+            const uint32_t p_v = sync[SY_POS0], m_v = sync[SY_MF0], e_v = sync[SY_LEN_END], f_v = sync[SY_FAR_HI];
+            far_hi = U(f_v);
+            LoopExit ex;
+            (void)parse_loop(2, U(p_v), U(m_v), U(e_v), ex);
+            if (dead) return;
+            sy_signal(SY_JOIN, seq);
+        }
+    }
+    LZ_HD void publish_exit(const LoopExit &ex) {
+        if (one()) {
+            sync[SY_EX_CUR] = ex.cur, sync[SY_EX_LONG] = ex.long_match;
+            sync[SY_EX_LEN] = ex.longest_len, sync[SY_EX_DIST] = ex.last_dist;
+        }
+        sy_signal(SY_EXIT, 1);
+    }
+
+    // Literal and short rep of position cur into entry cur + 1 (:598-624): nxr is that entry
+    // before, the result says what to write and whether the literal won (nextIsChar).
+    struct NextUpd {
+        uint32_t price, back, pp;
+        bool changed, next_is_char;
+    };
+    LZ_HD NextUpd merge_next(const Rec &nxr, uint32_t cur, uint32_t cur_and1, uint32_t short_rep, bool same_byte) const {
+        NextUpd u;
+        u.price = nxr.price, u.back = 0, u.pp = 0, u.changed = false, u.next_is_char = false;
+        if (cur_and1 < u.price) {
+            u.price = cur_and1, u.back = 0xFFFFFFFFu, u.pp = cur;
+            u.next_is_char = true, u.changed = true;
+        }
+        if (same_byte) {
+            bool blocked;
+            if (u.changed)
+                blocked = false;  // posPrev == cur is not < cur
+            else
+                blocked = (nxr.pp & 0xFFF) < cur && nxr.back == 0;
+            if (!blocked && short_rep <= u.price) {
+                u.price = short_rep, u.back = 0, u.pp = cur;
+                u.next_is_char = true, u.changed = true;
             }
-            win_advance(cur);
+        }
+        return u;
+    }
+
+    // The main loop of a parse (:507-795), positions first_cur, first_cur + step, ...: every
+    // position for a wave of its own, every other one in a cooperative workgroup.
+    //
+    // Two waves (COOP).  What position c does falls into a first half S(c) -- match list, state
+    // and reps of the path into c, state prices, the round, the literal / short-rep candidate for
+    // entry c + 1 -- and a second half A(c), the apply phase over entries c + 2 and beyond.
+    // S(c) needs entry c final: the apply phases up to A(c - 2), which the same wave ran, and the
+    // literal candidate of c - 1, which the other wave publishes at the end of S(c - 1) and this
+    // wave merges into entry c itself (that candidate comes after those of A(c - 2) in the
+    // reference's order, and A(c - 1), still running, does not touch entry c).  A(c) needs
+    // A(c - 1), which changes the same entries.  So S(c + 1) runs beside A(c), and a position
+    // costs about half of what it costs one wave.  The end of the parse range (cur == lenEnd) is
+    // known when A(c - 1) is done: a wave runs S(c) before it knows whether c is parsed at all
+    // (entry c is final and valid in either case), checks, and only then lets the other wave go
+    // on to c + 1.  Returns true in the wave that found the end (ex is set), false in the other.
+    LZ_HD bool parse_loop(uint32_t first_cur, const uint32_t pos0, const uint32_t mf0, uint32_t len_end,
+                          LoopExit &ex) {
+        const uint32_t fb = ep.fb;
+        constexpr uint32_t kStep = COOP ? 2 : 1;
+        LZ_LANEVAR(x0);
+        LZ_LANEVAR(x1);
+        LZ_LANEVAR(x2);
+        LZ_LANEVAR(x3);
+        ApplyIn A;
+        uint32_t r0, r1, r2, r3, ps, rep_len1, rep_match_price, nmp;
+        uint32_t cur = first_cur - kStep;
+        for (;;) {
+            cur += kStep;
+            if constexpr (!COOP) {
+                if (cur == len_end) {
+                    ex.cur = cur, ex.long_match = 0, ex.longest_len = 0, ex.last_dist = 0;
+                    return true;
+                }
+                win_advance(cur);
+            } else {
+                win_set(cur);
+                mfpos = mf0 + cur - 1;
+            }
             LZ_LAP(5)
-            uint32_t new_len = read_match_distances();
+            // COOP: a wave may get here for a position beyond the end of the chunk or of the
+            // optimum table; the parse then ends at this position at the latest
+            const bool beyond = COOP && (mfpos >= n || cur >= kNumOpts - 1);
+            uint32_t new_len = 0;
+            if (!beyond) new_len = read_match_distances();
             LZ_LAP(0)
-            dpairs = dist_pairs;
-            if (new_len >= fb) {
-                longest_len = new_len;
-                longest_found = 1;
-                commit_from_window(cur);
-                return backward(cur);
+            uint32_t dpairs = beyond ? 0 : dist_pairs;
+            Rec rc_, nxr;
+            if constexpr (COOP) {
+                if (!sy_wait(SY_S, cur - 1)) return false;
+                const Rec rc_v = o_rec[cur & (kRecWin - 1)];
+                rc_ = urec(rc_v);
+                if (cur > 1) {  // the literal candidate of cur - 1 (entry 1 was set before the loop)
+                    const uint32_t par = (cur - 1) & 1;
+                    const uint32_t a_v = sync[SY_PKT_PRICE + par], s_v = sync[SY_PKT_SP + par], q_v = sync[SY_PKT_EQ + par];
+                    const NextUpd u = merge_next(rc_, cur - 1, U(a_v), U(s_v), U(q_v) != 0);
+                    if (u.changed) {
+                        rc_.price = u.price, rc_.back = u.back, rc_.pp = u.pp;
+                        u_set_pbp(cur, u.price, u.back, u.pp);
+                    }
+                    if (one()) sync[SY_NIC + par] = u.next_is_char;
+                    sy_signal(SY_M, cur - 1);
+                }
+                if (beyond || new_len >= fb) {
+                    if (!sy_wait(SY_A, cur - 1)) return false;
+                    const uint32_t e_v = sync[SY_LEN_END];
+                    const bool at_end = cur == U(e_v);  // comes first in the reference's order
+                    ex.cur = cur, ex.long_match = !at_end, ex.longest_len = new_len;
+                    ex.last_dist = at_end ? 0 : U(mdist[dpairs - 1]);
+                    publish_exit(ex);
+                    return true;
+                }
+            } else {
+                if (new_len >= fb) {
+                    longest_len = new_len;
+                    longest_found = 1;
+                    ex.cur = cur, ex.long_match = 1, ex.longest_len = new_len, ex.last_dist = 0;
+                    return true;
+                }
             }
-            position++;
+            const uint32_t position = pos0 + cur;
             // what is left of the chunk and of the optimum table bounds every length from here (:627, :724-731)
             uint32_t avail_full = kNumOpts - 1 - cur;
             if (avail() + 1 < avail_full) avail_full = avail() + 1;
@@ -1052,8 +1308,10 @@ struct Encoder {
             // ---- state and reps of the path that reaches cur (:525-597).  The entry E the
             // path comes from always holds the reps to permute (for a literal or short rep it
             // is cur-1, whose reps are the current ones).
-            const Rec rc_v = o_rec[cur & (kRecWin - 1)], nxr_v = o_rec[(cur + 1) & (kRecWin - 1)];
-            const Rec rc_ = urec(rc_v), nxr = urec(nxr_v);
+            if constexpr (!COOP) {
+                const Rec rc_v = o_rec[cur & (kRecWin - 1)], nxr_v = o_rec[(cur + 1) & (kRecWin - 1)];
+                rc_ = urec(rc_v), nxr = urec(nxr_v);
+            }
             const uint32_t cw = rc_.pp;
             uint32_t pos_prev = cw & 0xFFF;
             const bool c_p1 = (cw & kPpPrev1) != 0, c_p2 = (cw & kPpPrev2) != 0;
@@ -1243,29 +1501,37 @@ struct Encoder {
             // ---- literal and short rep into entry cur+1 (:598-624)
             const uint32_t cur_byte = LZ_FROM_LANE(x0, 4), match_byte = LZ_FROM_LANE(x1, 4), lit_l2 = LZ_FROM_LANE(x3, 4);
             const uint32_t cur_and1 = cur_price + p_im0 + LZ_FROM_LANE(x2, 4);
-            uint32_t nx_price = nxr.price;
-            bool next_is_char = false, nx_changed = false;
-            uint32_t nx_back = 0, nx_pp = 0;
-            if (cur_and1 < nx_price) {
-                nx_price = cur_and1, nx_back = 0xFFFFFFFFu, nx_pp = cur;
-                next_is_char = true, nx_changed = true;
-            }
-            if (match_byte == cur_byte) {
-                bool blocked;
-                if (nx_changed)
-                    blocked = false;  // posPrev == cur is not < cur
-                else
-                    blocked = (nxr.pp & 0xFFF) < cur && nxr.back == 0;
-                if (!blocked) {
-                    const uint32_t sp = rep_match_price + rep_len1;
-                    if (sp <= nx_price) {
-                        nx_price = sp, nx_back = 0, nx_pp = cur;
-                        next_is_char = true, nx_changed = true;
-                    }
+            const uint32_t short_rep = rep_match_price + rep_len1;
+            bool next_is_char;
+            if constexpr (!COOP) {
+                const NextUpd u = merge_next(nxr, cur, cur_and1, short_rep, match_byte == cur_byte);
+                if (u.changed) u_set_pbp(cur + 1, u.price, u.back, u.pp);
+                next_is_char = u.next_is_char;
+                if (!do_rest) continue;
+            } else {
+                // is this position parsed at all?  Known when A(cur - 1) is done.
+                if (!sy_wait(SY_A, cur - 1)) return false;
+                const uint32_t e_v = sync[SY_LEN_END], f_v = sync[SY_FAR_HI];
+                len_end = U(e_v), far_hi = U(f_v);
+                if (cur == len_end) {
+                    ex.cur = cur, ex.long_match = 0, ex.longest_len = 0, ex.last_dist = 0;
+                    publish_exit(ex);
+                    return true;
+                }
+                if (one()) {
+                    sync[SY_PKT_PRICE + (cur & 1)] = cur_and1, sync[SY_PKT_SP + (cur & 1)] = short_rep;
+                    sync[SY_PKT_EQ + (cur & 1)] = match_byte == cur_byte;
+                }
+                sy_signal(SY_S, cur);
+                if (!sy_wait(SY_M, cur)) return false;
+                const uint32_t n_v = sync[SY_NIC + (cur & 1)];
+                next_is_char = U(n_v) != 0;
+                win_enter(cur);
+                if (!do_rest) {
+                    sy_signal(SY_A, cur);  // len_end and far_hi stay as they are
+                    continue;
                 }
             }
-            if (nx_changed) u_set_pbp(cur + 1, nx_price, nx_back, nx_pp);
-            if (!do_rest) continue;
             LZ_LAP(9)
 
             // ---- continuation of the literal (:635-658)
@@ -1334,6 +1600,10 @@ struct Encoder {
             note_far(new_end);
             LZ_LAP(4)
             len_end = new_end;
+            if constexpr (COOP) {
+                if (one()) sync[SY_LEN_END] = len_end, sync[SY_FAR_HI] = far_hi;
+                sy_signal(SY_A, cur);
+            }
         }
     }
 
@@ -1407,6 +1677,9 @@ struct Encoder {
         for (;;) {
             LZ_LAP(7)
             uint32_t len = get_optimum(now_pos);
+            if constexpr (COOP) {
+                if (dead) return;  // finished is set: the chunk ends here with an error status
+            }
             LZ_LAP(6)
             uint32_t pos = back_res;
             uint32_t ps = now_pos & pos_state_mask;
@@ -1502,6 +1775,7 @@ struct Encoder {
         cache = 0;
         range = 0xFFFFFFFFu;
         overflow = 0;
+        dead = 0;
         mfpos = 0;
         longest_len = dist_pairs = add_offset = opt_end = opt_cur = longest_found = 0;
         now_pos = 0;
@@ -1521,6 +1795,7 @@ struct Encoder {
         fill_align_prices();
         do code_one_block();
         while (!finished);
+        if constexpr (COOP) sy_signal(SY_FORK, kSyDone);
     }
 };
 

@@ -5,6 +5,7 @@
 #define LZ_HOSTSIM 1
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../lzma_amd/csrc/lzma_dec_core.hpp"
@@ -85,9 +86,10 @@ struct ChainMFRef {
 };
 }  // namespace
 
-extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
-                         uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
-                         size_t *out_n) {
+template <bool COOP>
+static int hs_encode_impl(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
+                          uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
+                          size_t *out_n) {
     std::vector<uint8_t> padded(in, in + n);
     padded.resize(n + 16, 0);
     ChainMF cm;
@@ -104,7 +106,9 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     std::vector<lz::Reps> opt_bks(lz::kBksWin);
     std::vector<uint32_t> small(lz::enc_small_words(fb, pb));
     lz::build_prob_prices(pp.data(), 0, 1);
-    lz::Encoder<ChainMFRef, lz::prob_t *> e;
+    std::vector<uint32_t> sync(lz::SY_WORDS, 0), own1(lz::la_words(fb) + lz::mdist_words(fb));
+    lz::Encoder<ChainMFRef, lz::prob_t *, COOP> e;
+    e.sync = sync.data();
     e.data = padded.data();
     e.n = (uint32_t)n;
     e.readable = (uint32_t)n;  // exercises the byte-wise tail of match_len
@@ -121,7 +125,27 @@ extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_
     e.ep = ep;
     e.lane_id = 0;
     lz::write_header(out, ep, eos ? -1 : (int64_t)n);
-    e.run(small.data());
+    if (COOP) {
+        // the second wave of a cooperative workgroup is a second thread over the same memory
+        lz::Encoder<ChainMFRef, lz::prob_t *, COOP> h = e;
+        std::thread t([&] { h.helper_run(small.data(), own1.data()); });
+        e.run(small.data());
+        t.join();
+    } else {
+        e.run(small.data());
+    }
     *out_n = lz::kHeaderSize + e.out_n;
-    return e.overflow ? lz::ST_OUT_CAP : lz::ST_OK;
+    return e.dead ? lz::ST_HIP : (e.overflow ? lz::ST_OUT_CAP : lz::ST_OK);
+}
+
+extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
+                         uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
+                         size_t *out_n) {
+    return hs_encode_impl<false>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
+}
+// the same through the cooperative parse loop, one thread per wave
+extern "C" int hs_encode_coop(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
+                              uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
+                              size_t *out_n) {
+    return hs_encode_impl<true>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
 }
