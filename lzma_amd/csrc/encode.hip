@@ -173,11 +173,19 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
         e.mf = MfFunctor<PACKED, COOP ? 2 : 1>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
         e.ep = ep;
 #if defined(LZ_PROFILE)
-        for (int i = 0; i < 12; i++) e.prof[i] = 0;
+        for (int i = 0; i < 16; i++) e.prof[i] = 0;
         e.prof_last = __builtin_readcyclecounter();
 #endif
         if (COOP && wave != 0) {
             e.helper_run(small, (LZ_LDS uint32_t *)(sm + L.own1));
+#if defined(LZ_PROFILE)
+            if (lane == 0 && blockIdx.x == 0)
+                printf("PROF wave 1: mf %llu | wait-S %llu | path %llu | prices %llu | round-loads %llu | round %llu | lit %llu | wait-A %llu | wait-M %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | other %llu | idle %llu\n",
+                       (unsigned long long)e.prof[0], (unsigned long long)e.prof[12], (unsigned long long)e.prof[8], (unsigned long long)e.prof[1],
+                       (unsigned long long)e.prof[11], (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[13],
+                       (unsigned long long)e.prof[14], (unsigned long long)e.prof[10], (unsigned long long)e.prof[3], (unsigned long long)e.prof[4],
+                       (unsigned long long)e.prof[5], (unsigned long long)e.prof[6], (unsigned long long)e.prof[15]);
+#endif
             continue;
         }
         e.run(small);
@@ -188,6 +196,9 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
                    (unsigned long long)e.prof[11], (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[10],
                    (unsigned long long)e.prof[3], (unsigned long long)e.prof[4], (unsigned long long)e.prof[5],
                    (unsigned long long)e.prof[6], (unsigned long long)e.prof[7]);
+        if (COOP && lane == 0 && blockIdx.x == 0)
+            printf("PROF wave 0: wait-S %llu | wait-A %llu | wait-M %llu | join %llu\n", (unsigned long long)e.prof[12],
+                   (unsigned long long)e.prof[13], (unsigned long long)e.prof[14], (unsigned long long)e.prof[15]);
 #endif
         if (lane == 0) {
             lz::write_header(out + ob, ep, ep.eos ? -1 : (int64_t)e.n);

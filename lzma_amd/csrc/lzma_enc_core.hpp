@@ -109,8 +109,15 @@ LZ_D uint32_t lz_wave_max(uint32_t v) {
     const uint32_t x = a > b ? a : b, y = c > d ? c : d;
     return x > y ? x : y;
 }
+LZ_D uint32_t lz_sum8(uint32_t v) {  // sum of lanes 0..7
+    v += lz_row_shr<1>(v);
+    v += lz_row_shr<2>(v);
+    v += lz_row_shr<4>(v);
+    return LZ_FROM_LANE(v, 7);
+}
 #define LZ_WAVE_MAX(name) lz_wave_max(name)
 #define LZ_WAVE_COUNT(name) ((uint32_t)__builtin_popcountll(__ballot((name) != 0)))
+#define LZ_SUM8(name) lz_sum8(name)
 #define LZ_LANES_BEGIN(L) { const uint32_t L = lane_id;
 #define LZ_LANES_END }
 #else
@@ -130,6 +137,12 @@ inline uint32_t lz_wave_count_host(const uint32_t *v) {
     return m;
 }
 #define LZ_WAVE_COUNT(name) lz_wave_count_host(name)
+inline uint32_t lz_sum8_host(const uint32_t *v) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < 8; i++) m += v[i];
+    return m;
+}
+#define LZ_SUM8(name) lz_sum8_host(name)
 #define LZ_LANES_BEGIN(L) for (uint32_t L = 0; L < kLanes; L++) {
 #define LZ_LANES_END }
 #endif
@@ -235,13 +248,21 @@ constexpr uint32_t kSyDone = 0xFFFFFFFFu;
 // Flag accesses between the waves of a workgroup.  Data written before lz_sy_store is visible
 // to a wave that has seen the stored value with lz_sy_load.
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+// The waves of a workgroup share their CU's LDS and first-level cache, so a reader needs no
+// more than to issue its accesses after it has seen the flag.  A writer whose data is in LDS
+// alone needs no wait either (a wave's LDS instructions are performed in order: the data is
+// there before the flag); one that has written to HBM as well waits for those stores first
+// (hbm_too).
 LZ_D uint32_t lz_sy_load(const LZ_LDS uint32_t *p) {
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const volatile LZ_LDS uint32_t *)p);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return v;
 }
-LZ_D void lz_sy_store(LZ_LDS uint32_t *p, uint32_t v, bool one_lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+LZ_D void lz_sy_store(LZ_LDS uint32_t *p, uint32_t v, bool one_lane, bool hbm_too = true) {
+    if (hbm_too)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (one_lane) *(volatile LZ_LDS uint32_t *)p = v;
 }
 LZ_D void lz_sy_pause() { __builtin_amdgcn_s_sleep(1); }
@@ -250,7 +271,7 @@ LZ_D void lz_sy_pause() { __builtin_amdgcn_s_sleep(1); }
 #include <sched.h>
 namespace lz {
 inline uint32_t lz_sy_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-inline void lz_sy_store(uint32_t *p, uint32_t v, bool) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline void lz_sy_store(uint32_t *p, uint32_t v, bool, bool = true) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline void lz_sy_pause() { sched_yield(); }
 #endif
 
@@ -281,7 +302,7 @@ struct Encoder {
     PriceLayout pl;
     uint32_t lane_id;
 #if defined(LZ_PROFILE)
-    uint64_t prof[12], prof_last;
+    uint64_t prof[16], prof_last;
 #endif
 
     // ---- prices that depend only on (state, posState)
@@ -508,7 +529,9 @@ struct Encoder {
             lz_sy_pause();
         }
     }
-    LZ_HD void sy_signal(uint32_t which, uint32_t v) { lz_sy_store(sync + which, v, one()); }
+    LZ_HD void sy_signal(uint32_t which, uint32_t v, bool hbm_too = true) {
+        lz_sy_store(sync + which, v, one(), hbm_too);
+    }
 
     // ------------------------------------------------------------ range coder
     LZ_HD void rc_put(uint32_t b) {
@@ -1001,6 +1024,9 @@ struct Encoder {
             if (t.lt_pair < avail_full) t.lim2 = avail_full - 1 - t.lt_pair < fb ? avail_full - 1 - t.lt_pair : fb;
         }
         t.active = t.is_rep || t.is_lit || (t.is_pair && t.lim2 != 0);
+        // a cooperative wave may run a position whose entry nothing was written to (parse_loop):
+        // its stale distances must not be followed out of the buffer
+        if (COOP && t.dist >= t.a_off) t.active = false;
         return t;
     }
 
@@ -1117,15 +1143,18 @@ struct Encoder {
         if constexpr (COOP) {
             // hand the loop to both waves: this one takes the odd positions
             const uint32_t mf0 = mfpos, add0 = add_offset;
+            lz_sy_store(sync + SY_EXIT, 0, one());  // (the waiting wave polls this word)
             if (one()) {
-                sync[SY_S] = 0, sync[SY_A] = 0, sync[SY_M] = 0, sync[SY_EXIT] = 0;
+                sync[SY_S] = 0, sync[SY_A] = 0, sync[SY_M] = 0;
                 sync[SY_LEN_END] = len_end, sync[SY_FAR_HI] = far_hi;
                 sync[SY_POS0] = position, sync[SY_MF0] = mf0;
             }
             const uint32_t seq = lz_sy_load(sync + SY_FORK) + 1;
             sy_signal(SY_FORK, seq);
             const bool mine = parse_loop(1, position, mf0, len_end, ex);
+            LZ_LAP(6)
             (void)sy_wait_word(SY_JOIN, seq, false);
+            LZ_LAP(15)
             if (dead) {  // the waves lost each other: end the chunk, which reports the error
                 back_res = 0xFFFFFFFFu;
                 return 1;
@@ -1166,7 +1195,9 @@ struct Encoder {
         dead = 0;
         for (;;) {
             // (wave 0 codes the symbols of a parse between two loops: this wait is the long one)
+            LZ_LAP(6)
             const uint32_t f = sy_wait_word(SY_FORK, seq, true);
+            LZ_LAP(15)
             if (dead || f == kSyDone) return;
             seq = f;
             const uint32_t p_v = sync[SY_POS0], m_v = sync[SY_MF0], e_v = sync[SY_LEN_END], f_v = sync[SY_FAR_HI];
@@ -1254,13 +1285,30 @@ struct Encoder {
             // COOP: a wave may get here for a position beyond the end of the chunk or of the
             // optimum table; the parse then ends at this position at the latest
             const bool beyond = COOP && (mfpos >= n || cur >= kNumOpts - 1);
+            const uint32_t position = pos0 + cur;
+            // COOP: what the literal's price needs from the data alone is fetched by lanes 0..7
+            // before anything is waited for: the byte, the byte before it, and each lane's model
+            // for its bit of the byte when the literal is coded without a match byte
+            LZ_LANEVAR(cb8);
+            LZ_LANEVAR(sub8);
+            LZ_LANEVAR(np8);
+            if constexpr (COOP) {
+                if (!beyond) {
+                    LZ_LANES_BEGIN(L)
+                    if (L < 8) {
+                        const uint8_t *a = data + mfpos;
+                        const uint32_t cb = a[0], sub = lit_sub(position, a[-1]);
+                        LZ_LV(cb8, L) = cb, LZ_LV(sub8, L) = sub;
+                        LZ_LV(np8, L) = lit[sub + ((0x100u | cb) >> (8 - L))];
+                    }
+                    LZ_LANES_END
+                }
+            }
             uint32_t new_len = 0;
-            if (!beyond) new_len = read_match_distances();
-            LZ_LAP(0)
-            uint32_t dpairs = beyond ? 0 : dist_pairs;
             Rec rc_, nxr;
             if constexpr (COOP) {
                 if (!sy_wait(SY_S, cur - 1)) return false;
+                LZ_LAP(12)
                 const Rec rc_v = o_rec[cur & (kRecWin - 1)];
                 rc_ = urec(rc_v);
                 if (cur > 1) {  // the literal candidate of cur - 1 (entry 1 was set before the loop)
@@ -1272,8 +1320,14 @@ struct Encoder {
                         u_set_pbp(cur, u.price, u.back, u.pp);
                     }
                     if (one()) sync[SY_NIC + par] = u.next_is_char;
-                    sy_signal(SY_M, cur - 1);
+                    sy_signal(SY_M, cur - 1, false);
                 }
+                LZ_LAP(8)
+            }
+            if (!beyond) new_len = read_match_distances();
+            LZ_LAP(0)
+            uint32_t dpairs = beyond ? 0 : dist_pairs;
+            if constexpr (COOP) {
                 if (beyond || new_len >= fb) {
                     if (!sy_wait(SY_A, cur - 1)) return false;
                     const uint32_t e_v = sync[SY_LEN_END];
@@ -1291,7 +1345,6 @@ struct Encoder {
                     return true;
                 }
             }
-            const uint32_t position = pos0 + cur;
             // what is left of the chunk and of the optimum table bounds every length from here (:627, :724-731)
             uint32_t avail_full = kNumOpts - 1 - cur;
             if (avail() + 1 < avail_full) avail_full = avail() + 1;
@@ -1316,13 +1369,15 @@ struct Encoder {
             uint32_t pos_prev = cw & 0xFFF;
             const bool c_p1 = (cw & kPpPrev1) != 0, c_p2 = (cw & kPpPrev2) != 0;
             const uint32_t c_bp = rc_.back;
-            const uint32_t E = (c_p1 && c_p2) ? ((cw >> 12) & 0xFFF) : (c_p1 ? pos_prev - 1 : pos_prev);
+            uint32_t E = (c_p1 && c_p2) ? ((cw >> 12) & 0xFFF) : (c_p1 ? pos_prev - 1 : pos_prev);
+            if constexpr (COOP) E &= kNumOpts - 1;  // (a stale entry, see round_task)
             const uint32_t e_pp_v = opp(E);
             const Reps eb_v = gbks(E);
             const uint32_t e_pp = U(e_pp_v);
             const Reps eb = ureps(eb_v);
             LZ_LAP(8)
             uint32_t st = (e_pp >> 24) & 0xF;
+            if constexpr (COOP) st = st < kNumStates ? st : kNumStates - 1;
             if (c_p1) {
                 pos_prev--;
                 if (c_p2) st = rc_.back2 < kNumReps ? st_rep(st) : st_match(st);
@@ -1380,6 +1435,37 @@ struct Encoder {
                 rep_len1 = spc.rep_len1;
             }
             LZ_LAP(1)
+            uint32_t cur_and1 = 0;
+            const uint32_t short_rep = rep_match_price + rep_len1;
+            if constexpr (COOP) {
+                // The other wave waits for this position's literal / short-rep candidate and for
+                // nothing else of it: that comes first, the literal's eight bits priced by
+                // eight lanes, and goes out before the round.
+                LZ_LANEVAR(lp8);
+                LZ_LANEVAR(eq8);
+                const uint32_t a_off = mfpos - 1;
+                const bool mode = !st_is_char(st);
+                LZ_LANES_BEGIN(L)
+                if (L < 8) {
+                    const uint32_t cb = LZ_LV(cb8, L);
+                    const uint32_t mb = r0 < a_off ? data[a_off - r0 - 1] : 0;
+                    const uint32_t i = 7 - L;
+                    uint32_t model = LZ_LV(np8, L);
+                    if (mode && ((cb ^ mb) >> (i + 1)) == 0)  // the higher bits equal the match byte's
+                        model = lit[LZ_LV(sub8, L) + ((1 + ((mb >> i) & 1)) << 8) + ((0x100u | cb) >> (i + 1))];
+                    LZ_LV(lp8, L) = price_bit(model, (cb >> i) & 1);
+                    LZ_LV(eq8, L) = cb == mb;
+                }
+                LZ_LANES_END
+                cur_and1 = cur_price + p_im0 + LZ_SUM8(lp8);
+                const uint32_t same = LZ_FROM_LANE(eq8, 0);
+                if (one()) {
+                    sync[SY_PKT_PRICE + (cur & 1)] = cur_and1, sync[SY_PKT_SP + (cur & 1)] = short_rep;
+                    sync[SY_PKT_EQ + (cur & 1)] = same;
+                }
+                sy_signal(SY_S, cur, false);
+            }
+            LZ_LAP(9)
             // ---- the round: every lane runs the same code on its own task.
             //   lanes 0-3: rep match L (:661-663) and its continuation (:689-721)
             //   lane 4:    the literal (:599-603) and rep0 after it (:635-638)
@@ -1500,17 +1586,18 @@ struct Encoder {
             LZ_LAP(2)
             // ---- literal and short rep into entry cur+1 (:598-624)
             const uint32_t cur_byte = LZ_FROM_LANE(x0, 4), match_byte = LZ_FROM_LANE(x1, 4), lit_l2 = LZ_FROM_LANE(x3, 4);
-            const uint32_t cur_and1 = cur_price + p_im0 + LZ_FROM_LANE(x2, 4);
-            const uint32_t short_rep = rep_match_price + rep_len1;
             bool next_is_char;
             if constexpr (!COOP) {
+                cur_and1 = cur_price + p_im0 + LZ_FROM_LANE(x2, 4);
                 const NextUpd u = merge_next(nxr, cur, cur_and1, short_rep, match_byte == cur_byte);
                 if (u.changed) u_set_pbp(cur + 1, u.price, u.back, u.pp);
                 next_is_char = u.next_is_char;
                 if (!do_rest) continue;
             } else {
                 // is this position parsed at all?  Known when A(cur - 1) is done.
+                LZ_LAP(9)
                 if (!sy_wait(SY_A, cur - 1)) return false;
+                LZ_LAP(13)
                 const uint32_t e_v = sync[SY_LEN_END], f_v = sync[SY_FAR_HI];
                 len_end = U(e_v), far_hi = U(f_v);
                 if (cur == len_end) {
@@ -1518,12 +1605,8 @@ struct Encoder {
                     publish_exit(ex);
                     return true;
                 }
-                if (one()) {
-                    sync[SY_PKT_PRICE + (cur & 1)] = cur_and1, sync[SY_PKT_SP + (cur & 1)] = short_rep;
-                    sync[SY_PKT_EQ + (cur & 1)] = match_byte == cur_byte;
-                }
-                sy_signal(SY_S, cur);
                 if (!sy_wait(SY_M, cur)) return false;
+                LZ_LAP(14)
                 const uint32_t n_v = sync[SY_NIC + (cur & 1)];
                 next_is_char = U(n_v) != 0;
                 win_enter(cur);
