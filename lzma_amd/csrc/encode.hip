@@ -521,9 +521,11 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         hipStream_t es = S.enc[h.b % in_flight];
         const unsigned grid = std::min(h.nchunks, grid_cap);
         LZ_HIP_BAIL(hipEventRecord(sl.e0, es));
-        // Two waves per chunk when the chunks still to be encoded leave wave slots free: the
-        // call's last launches, and calls with few chunks altogether.
-        const bool coop = coop_mode == 1 || (coop_mode < 0 && 2 * (uint64_t)(n_chunks - cut[h.b]) <= resident);
+        // Two waves per chunk when the call has so few chunks that half of the wave slots
+        // would stay empty.  (Not for the last launches of a larger call: they run beside
+        // earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
+        // in sum than one does -- measured on 4096 chunks: 18.8 s against 15.8 s.)
+        const bool coop = coop_mode == 1 || (coop_mode < 0 && 2 * (uint64_t)n_chunks <= resident);
         auto fn = packed ? (coop ? launch_encode<true, true> : launch_encode<true, false>)
                          : (coop ? launch_encode<false, true> : launch_encode<false, false>);
         int r = fn(grid, coop ? LC.total : L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,

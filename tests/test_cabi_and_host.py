@@ -72,6 +72,7 @@ def hostsim():
     L.hs_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.hs_encode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p, C.c_size_t,
                                                                          C.POINTER(C.c_size_t)]
+    L.hs_encode_coop.argtypes = L.hs_encode.argtypes
     return L
 
 
@@ -82,11 +83,12 @@ def _hs_decode(L, stream, cap=1 << 20):
     return rc, out[: n.value].tobytes()
 
 
-def _hs_encode(L, raw, dict_log, fb, lc=3, lp=0, pb=2, eos=True):
+def _hs_encode(L, raw, dict_log, fb, lc=3, lp=0, pb=2, eos=True, coop=False):
     cap = len(raw) * 2 + 1024
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
-    rc = L.hs_encode(raw, len(raw), dict_log, fb, lc, lp, pb, int(eos), out.ctypes.data, cap, C.byref(n))
+    fn = L.hs_encode_coop if coop else L.hs_encode
+    rc = fn(raw, len(raw), dict_log, fb, lc, lp, pb, int(eos), out.ctypes.data, cap, C.byref(n))
     assert rc == 0
     return out[: n.value].tobytes()
 
@@ -107,13 +109,14 @@ def test_kernel_decode_core_on_host(hostsim, vectors, data_txt, data_lzma):
                                  (12, 5, 8, 4, 4, True), (14, 32, 4, 1, 3, False)])
 def test_kernel_encode_core_on_host(hostsim, data_txt, cfg):
     """The encoder kernel's core, compiled for the host with a brute-force exhaustive
-    finder, equals the oracle with the cut value raised, byte for byte."""
+    finder, equals the oracle with the cut value raised, byte for byte: as one wave, and as
+    the cooperative pair of waves (two host threads over the same memory)."""
     from oracle import oracle as O
     dl, fb, lc, lp, pb, eos = cfg
     for raw in (b"", b"a", b"hello world\n", data_txt[:80000]):
-        got = _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos)
         want = O.encode(raw, O.params(dict_log=dl, fb=fb, lc=lc, lp=lp, pb=pb, cut=1 << 30, eos=eos))
-        assert got == want
+        assert _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos) == want
+        assert _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos, coop=True) == want
 
 
 def test_exhaustive_cut_stays_within_one_percent(data_txt):
