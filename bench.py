@@ -140,18 +140,59 @@ def spawn_ranks(n):
     """Start n copies of this script, one per GPU, and relay rank 0's output.  Runs before
     anything in this process touches a GPU (no process that has initialised the GPU is ever
     replaced or forked here)."""
+    import collections
+    import threading
     port = os.environ.get("MASTER_PORT") or str(free_port())
-    procs = []
+    procs, tails, pumps = [], [], []
+
+    def pump(pipe, tail):  # a rank's stderr goes through as it comes; its last lines are kept
+        for ln in pipe:
+            tail.append(ln)
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + sys.argv[1:],
-                                      env=env))
-    rc = 0
+        p = subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                             stderr=subprocess.PIPE, text=True, errors="replace")
+        tail = collections.deque(maxlen=25)
+        t = threading.Thread(target=pump, args=(p.stderr, tail), daemon=True)
+        t.start()
+        procs.append(p), tails.append(tail), pumps.append(t)
+    # A rank that dies leaves the others waiting in their next collective: the first non-zero
+    # exit ends the run with that rank's code instead of a time-out.  (Children are only
+    # started and stopped here; no process that has touched a GPU is ever replaced.)
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+                break
+        else:
+            time.sleep(0.2)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is None:
+        for t in pumps:
+            t.join(timeout=5)
+        return 0
+    rc = procs[failed].returncode
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    return rc
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    for t in pumps:
+        t.join(timeout=5)
+    sys.stderr.write(f"[bench] rank {failed} exited with code {rc}; the other ranks were stopped.  "
+                     f"Its last lines:\n" + "".join("    " + ln for ln in tails[failed]))
+    sys.stderr.flush()
+    return rc if rc > 0 else 1
 
 
 COLL_CPU = False  # collectives on CPU tensors (gloo) although the work runs on a GPU: --rehearse
@@ -356,6 +397,8 @@ class DecodeWorkload:
         sizes_all, is_log_all = mixed_streams(total_streams, 4096, 65536)
         s0, s1 = parallel.shard_by_bytes(sizes_all, rank, world)
         self.s0, self.ns = s0, s1 - s0
+        self.rank = rank
+        self.counts = [b - a for a, b in (parallel.shard_by_bytes(sizes_all, r, world) for r in range(world))]
         sizes = sizes_all[s0:s1]
         self.raw_sizes = sizes
         self.n = int(sizes.sum())
@@ -419,6 +462,11 @@ class DecodeWorkload:
                                                       self.d_out.data_ptr(), self.out_off.data_ptr(),
                                                       self.sizes.data_ptr(), self.status.data_ptr(), None))
             self.kernel_ms.append(N.last_timing())
+        # the streams end with a marker, their headers carry no size: where a stream's bytes go
+        # in the output of the whole batch is known only when every rank's sizes are
+        allsz = parallel.gather_ragged(self.sizes.cpu() if COLL_CPU else self.sizes, self.counts, self.rank,
+                                       self.world)
+        self.offsets = parallel.container_offsets(allsz)
 
     def units(self):
         return self.n
@@ -426,6 +474,10 @@ class DecodeWorkload:
     def verify(self):
         assert bool((self.status == 0).all().item())
         assert torch.equal(self.d_out[: self.n], self.d_raw), "decoded bytes differ from the raw input"
+        assert torch.equal(self.sizes.cpu(), torch.from_numpy(np.asarray(self.raw_sizes, dtype=np.int64)))
+        assert self.offsets.numel() == self.total + 1
+        lo = int(self.offsets[self.s0].item())
+        assert int(self.offsets[self.s0 + self.ns].item()) - lo == self.n
 
     def roofline(self):
         if not self.kernel_ms:
@@ -579,6 +631,8 @@ class StubWorkload:
         self.offsets = None
 
     def step(self):
+        if os.environ.get("BENCH_STUB_FAIL_RANK") == str(self.rank):  # (tests: a rank that dies mid-run)
+            raise RuntimeError(f"stub: rank {self.rank} fails on purpose")
         allsz = parallel.gather_sizes(self.sizes, self.total, self.rank, self.world)
         self.offsets = parallel.container_offsets(allsz)
 

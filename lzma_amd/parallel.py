@@ -55,11 +55,20 @@ def gather_sizes(local_sizes: torch.Tensor, n_items: int, rank: int, world: int,
 
     local_sizes holds the sizes of this rank's shard_range(n_items, rank, world).
     """
+    return gather_ragged(local_sizes, shard_counts(n_items, world), rank, world, group)
+
+
+def gather_ragged(local_sizes: torch.Tensor, counts, rank: int, world: int, group=None):
+    """All ranks' values in rank order, rank r contributing counts[r] of them (every rank passes
+    the same `counts`): one all-gather, padded to the widest share when the shares differ.
+    Used with shard_by_bytes, whose shares differ in length by design."""
     local_sizes = local_sizes.to(torch.int64)
     if world == 1:
         return local_sizes
     import torch.distributed as dist
-    counts = shard_counts(n_items, world)
+    counts = [int(c) for c in counts]
+    if len(counts) != world:
+        raise ValueError(f"{len(counts)} counts for {world} ranks")
     if local_sizes.numel() != counts[rank]:
         raise ValueError(f"rank {rank} holds {local_sizes.numel()} sizes, its shard has {counts[rank]}")
     width = max(counts)

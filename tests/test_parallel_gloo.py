@@ -74,6 +74,38 @@ def test_two_rank_container(n_chunks):
     assert got == want
 
 
+def _decode_worker(rank, world, port, q):
+    """The decode workload's exchange: streams sharded by raw bytes (shares of different length),
+    every rank decodes its own (oracle here), the sizes of all streams go round in one all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        raws = _chunks(13)
+        p = O.params(3, eos=True)
+        sizes = np.array([len(r) for r in raws])
+        spans = [parallel.shard_by_bytes(sizes, r, world) for r in range(world)]
+        b, e = spans[rank]
+        mine = [O.decode(O.encode(r, p))[1] for r in raws[b:e]]
+        local = torch.tensor([len(m) for m in mine], dtype=torch.int64)
+        allsz = parallel.gather_ragged(local, [y - x for x, y in spans], rank, world)
+        q.put((rank, allsz.tolist(), parallel.container_offsets(allsz).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_decode_sizes():
+    O.lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_decode_worker, args=(2, _free_port(), q), nprocs=2, join=True)
+    got = sorted(q.get() for _ in range(2))
+    want = [len(r) for r in _chunks(13)]
+    for rank, sizes, off in got:
+        assert sizes == want and off[-1] == sum(want) and len(off) == 14
+    with pytest.raises(ValueError):
+        parallel.gather_ragged(torch.zeros(3, dtype=torch.int64), [3], 0, 2)
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 5, 4096, 4099):
         for world in (1, 2, 3, 8):
@@ -183,3 +215,22 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_stops_when_a_rank_dies():
+    """A rank that raises leaves the other one waiting in the size exchange: bench.py must end
+    within seconds with a non-zero code and the dead rank's last lines, not hang."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_STUB_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "stub",
+                        "--backend", "gloo", "--steps", "3", "--warmup", "1", "--chunks", "11"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 60
+    assert "rank 1 exited with code" in r.stderr and "fails on purpose" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
