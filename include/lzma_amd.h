@@ -151,10 +151,19 @@ int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off, siz
  * workgroups' literal models, the list of streams with lc+lp > 3 that a second launch
  * decodes) lives in a device array of the library's own, about 58 MiB on every GPU the
  * library has run this call on, kept until the process ends; the call itself makes no
- * hipMalloc / hipFree.  Limits: at most 2^20 streams per call (more: LZMA_AMD_ERR_ARG);
- * 4096 workgroups, so about half the throughput of the allocating call on large batches.
- * Every call on a GPU uses that GPU's one array: calls that overlap in time on the same
- * GPU (from several threads or streams) race and must be serialised by the caller. */
+ * hipMalloc / hipFree.  Unlike every other entry point it does not wait for the device
+ * either: it enqueues a 256-byte memset and two kernels on `stream` and returns, so it can be
+ * recorded into a HIP graph; outputs, sizes and statuses are valid once the stream (or the
+ * graph launch) has completed.  The array's address is looked up once per device, by
+ * lzma_amd_set_device or by the first call on the device: do one of the two before a capture
+ * begins.  Limits: at most 2^20 streams per call (more: LZMA_AMD_ERR_ARG); 4096 workgroups in
+ * the first launch, so about half the throughput of the allocating call on large batches;
+ * streams with lc+lp > 3 (lc = 4 among them, which the allocating call decodes in its wide
+ * first launch) share nine workgroups in the second launch: a batch made of such streams
+ * decodes at a few hundredths of the allocating call's rate.  lzma_amd_last_timing reports
+ * zeros after this call.  Every call on a GPU uses that GPU's one array: calls that overlap in
+ * time on the same GPU (from several threads, streams or graph launches) race and must be
+ * serialised by the caller. */
 int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_streams,
                                       uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
                                       int32_t *d_status, void *stream);

@@ -34,7 +34,8 @@ int lzma_amd_device_count(void) {
 
 int lzma_amd_set_device(int device) {
     LZ_HIP(hipSetDevice(device));
-    return LZMA_AMD_OK;
+    // the one thing lzma_amd_decode_batch_dev_noalloc must not do later, inside a graph capture
+    return lzh::noalloc_prepare();
 }
 
 // levels table, lzma_encoder.go:97-108

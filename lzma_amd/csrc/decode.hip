@@ -145,6 +145,9 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
 // models of each workgroup and the list of streams deferred to the second launch -- lives
 // in a file-scope device array, so the call makes no hipMalloc/hipFree.  The array is
 // smaller than what lzma_amd_decode_batch_dev allocates, so fewer workgroups run at once.
+// The call only enqueues work on the caller's stream (a clearing memset and two kernels)
+// and never waits for the device, so it may be recorded into a graph; the address of the
+// array is looked up once per device, by lzma_amd_set_device or by the first call.
 namespace {
 constexpr uint32_t kNaLitLog = 3;                                // lc+lp handled by the first launch
 constexpr uint64_t kNaLitModels = 0x300ull << kNaLitLog;         // models per workgroup area
@@ -152,6 +155,9 @@ constexpr uint32_t kNaGrid = 4096;                               // workgroups o
 constexpr uint64_t kNaMaxStreams = 1ull << 20;                   // streams per call
 constexpr uint64_t kNaSmallBytes = kNaGrid * kNaLitModels * sizeof(lz::prob_t);  // 48 MiB
 constexpr uint64_t kNaBigBytes = kLitBig * sizeof(lz::prob_t);   // one full-size area, 6 MiB
+// the second launch runs when the first is done and its areas are dead: they serve again as
+// full-size areas, next to the one that follows them
+constexpr unsigned kNaBigGrid = (unsigned)(kNaSmallBytes / kNaBigBytes) + 1;  // 9 workgroups
 constexpr uint64_t kNaListBytes = (kNaMaxStreams + 64) * sizeof(uint32_t);
 constexpr uint64_t kNaScratchBytes = kNaSmallBytes + kNaBigBytes + kNaListBytes;
 static __device__ __align__(256) uint8_t scratch[kNaScratchBytes];
@@ -177,11 +183,19 @@ int na_scratch(uint8_t **out) {
 }
 }  // namespace
 
+// Looks the array up on the current device (a module load: not allowed inside a capture).
+int lzh::noalloc_prepare() {
+    uint8_t *p = nullptr;
+    return na_scratch(&p);
+}
+
 extern "C" int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint64_t *d_in_off,
                                                  size_t n_streams, uint8_t *d_out,
                                                  const uint64_t *d_out_off, uint64_t *d_out_sizes,
                                                  int32_t *d_status, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    lzh::tls().ms_total = lzh::tls().ms_finder = lzh::tls().ms_coder = 0.f;  // nothing is timed here
+    lzh::tls().coder_launches = 0;
     if (n_streams == 0) return LZMA_AMD_OK;
     if (!d_in || !d_in_off || !d_out || !d_out_off || !d_out_sizes || !d_status)
         return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
@@ -202,13 +216,15 @@ extern "C" int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint
                        (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small,
                        kNaLitModels, kNaLitLog);
     LZ_HIP(hipGetLastError());
-    // the second launch reads the count on the device: one workgroup with the full-size area
-    // takes the deferred streams in turn (none: it returns at once)
-    hipLaunchKernelGGL(decode_kernel<true>, dim3(1), dim3(64), 0, st, d_in, d_in_off, (uint64_t)n_streams,
-                       d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_big, kLitBig, kNaLitLog);
+    // the second launch reads the count on the device: nine workgroups with full-size areas (the
+    // first launch's areas, free again, and the one behind them) share the deferred streams
+    // (none: they return at once)
+    (void)lit_big;  // = lit_small + 8 full-size areas
+    hipLaunchKernelGGL(decode_kernel<true>, dim3(kNaBigGrid), dim3(64), 0, st, d_in, d_in_off, (uint64_t)n_streams,
+                       d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small, kLitBig, kNaLitLog);
     LZ_HIP(hipGetLastError());
-    LZ_HIP(hipStreamSynchronize(st));
-    return LZMA_AMD_OK;
+    lzh::tls().coder_launches = 2;
+    return LZMA_AMD_OK;  // results are there when the stream has run: the caller waits for it
 }
 
 extern "C" int lzma_amd_decode_batch(const uint8_t *in, const uint64_t *in_off, size_t n_streams,

@@ -463,7 +463,10 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     }
     // the sort temporaries go into the arena the scan is about to fill when that is large enough,
     // else into memory of their own
-    if (slots[0].res.arena.bytes < lzh::MfScratch::tmp_bytes((uint32_t)max_bytes))
+    // (every slot's arena: kept arenas differ in size once one of them has grown)
+    size_t min_arena = slots[0].res.arena.bytes;
+    for (int i = 1; i < nslots; i++) min_arena = std::min(min_arena, slots[i].res.arena.bytes);
+    if (min_arena < lzh::MfScratch::tmp_bytes((uint32_t)max_bytes))
         if ((rc = scratch.reserve_tmp((uint32_t)max_bytes))) return rc;
     lzh::Timer t_all;
     t_all.start(S.mf);

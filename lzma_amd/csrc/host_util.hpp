@@ -17,6 +17,7 @@ struct ThreadState {
     int coder_launches, coop_launches;
 };
 ThreadState &tls();
+int noalloc_prepare();  // decode.hip: address of the no-allocation entry point's device array
 int fail(int code, const char *fmt, ...);
 
 #define LZ_HIP(expr)                                                                      \

@@ -4,7 +4,8 @@ lzma_amd_decode_batch_dev_noalloc keeps what its kernels need beyond the caller'
 in a device array of the library's own.  Its statuses, sizes and bytes must equal those of
 lzma_amd_decode_batch_dev on the same batch, on two calls in a row (the second with a
 smaller batch: the array still holds the first call's contents), and a batch beyond its
-limit must be refused with a clear error.
+limit must be refused with a clear error.  The call only enqueues work, so the test waits
+for the device itself; around the second call the free device memory must not change.
 """
 import numpy as np
 import pytest
@@ -51,7 +52,16 @@ class _Hip:
         self.h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.h.hipFree.argtypes = [C.c_void_p]
+        self.h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         self.bufs = []
+
+    def free_bytes(self):
+        a, b = self.C.c_size_t(0), self.C.c_size_t(0)
+        assert self.h.hipMemGetInfo(self.C.byref(a), self.C.byref(b)) == 0
+        return a.value
+
+    def sync(self):
+        assert self.h.hipDeviceSynchronize() == 0
 
     def alloc(self, nbytes, fill=None):
         p = self.C.c_void_p()
@@ -94,14 +104,18 @@ def _run(entry, streams, caps):
         d_out = hip.alloc(int(out_off[-1]), fill=0)
         d_sizes, d_status = hip.alloc(8 * n, fill=0xFF), hip.alloc(4 * n, fill=0xFF)
         # every buffer exists before the call under test
+        hip.sync()
+        free0 = hip.free_bytes()
         N.check(entry(d_in, d_in_off, n, d_out, d_out_off, d_sizes, d_status, None))
+        hip.sync()  # the allocation-free entry point returns before the device is done
+        free1 = hip.free_bytes()
         sizes = hip.download(d_sizes, np.uint64, n)
         status = hip.download(d_status, np.int32, n)
         out = hip.download(d_out, np.uint8, int(out_off[-1]))
     finally:
         hip.free()
     outs = [out[int(out_off[i]): int(out_off[i]) + int(sizes[i])].tobytes() for i in range(n)]
-    return status, sizes, outs
+    return status, sizes, outs, free0 - free1
 
 
 def test_no_alloc_decode_equals_allocating_decode(data_txt):
@@ -112,8 +126,10 @@ def test_no_alloc_decode_equals_allocating_decode(data_txt):
         raws, streams = _batch(data_txt, n, seed)
         caps = [len(r) + 32 for r in raws]
         caps[5] = max(0, len(raws[5]) - 10)  # too small: ERR_OUT_CAP from both
-        st_a, sz_a, out_a = _run(L.lzma_amd_decode_batch_dev, streams, caps)
-        st_b, sz_b, out_b = _run(L.lzma_amd_decode_batch_dev_noalloc, streams, caps)
+        st_a, sz_a, out_a, _ = _run(L.lzma_amd_decode_batch_dev, streams, caps)
+        st_b, sz_b, out_b, taken = _run(L.lzma_amd_decode_batch_dev_noalloc, streams, caps)
+        if seed == 2:  # the array's address is known by now: the call must take no device memory
+            assert taken == 0, f"free device memory changed by {taken} bytes across the call"
         assert np.array_equal(st_a, st_b), (st_a, st_b)
         assert np.array_equal(sz_a, sz_b)
         assert out_a == out_b
