@@ -244,6 +244,43 @@ def reduce_ranks(x, world, dev, op):
     return float(t.item())
 
 
+_DEVICE_COPY = {}
+
+
+def device_copy_gbs(dev):
+    """Bytes read plus bytes written per second by a plain device-to-device copy of 1 GiB,
+    measured here with events on the current stream: what "all of the HBM bandwidth" means on
+    this very device, beside the vendor's 8 TB/s."""
+    if dev.type != "cuda":
+        return None
+    if dev.index not in _DEVICE_COPY:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device=dev)
+        b = torch.empty(n, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        _DEVICE_COPY[dev.index] = round(2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+    return _DEVICE_COPY[dev.index]
+
+
+def with_copy_rate(r, dev):
+    """Adds the measured device-copy rate and the fraction of it to a roofline object."""
+    if r is None:
+        return None
+    c = device_copy_gbs(dev)
+    if c:
+        r["device_copy"] = {"achieved": c, "unit": "GB/s", "what": "1 GiB device-to-device copy, read + written bytes"}
+        r["frac_of_device_copy"] = round(r["achieved"] / c, 8)
+    return r
+
+
 # ------------------------------------------------------------------ workloads
 class EncodeWorkload:
     """configs[2] (default) and configs[4] (`c5`): every chunk an independent .lzma stream."""
@@ -312,6 +349,40 @@ class EncodeWorkload:
         assert bool((st == 0).all().item()), "a GPU-encoded chunk did not decode"
         assert bool((osz == self.chunk).all().item())
         assert torch.equal(out, self.d_in), "round trip through the GPU decoder differs from the input"
+
+    def end_to_end(self):
+        """One step through the host entry point (lzma_amd_encode_chunks): input and output in
+        pinned host memory, the bytes crossing PCIe inside the timed region, copies on a stream
+        of their own beside the kernels.  One warm-up call (it sizes the kept staging buffers),
+        one timed; the sizes must equal those of the device-resident steps."""
+        N = native()
+        L = N.lib()
+        if not self.nchunks:
+            return None
+        cap = L.lzma_amd_encode_bound(self.chunk)
+        h_in = torch.from_numpy(self.host).pin_memory()
+        h_out = torch.empty(self.nchunks * cap, dtype=torch.uint8).pin_memory()
+        in_off = np.arange(0, self.n + 1, self.chunk, dtype=np.uint64)
+        out_off = np.arange(0, (self.nchunks + 1) * cap, cap, dtype=np.uint64)
+        sizes = np.zeros(self.nchunks, dtype=np.uint64)
+        status = np.zeros(self.nchunks, dtype=np.int32)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            N.check(L.lzma_amd_encode_chunks(h_in.data_ptr(), in_off.ctypes.data, self.nchunks, C.byref(self.params),
+                                             h_out.data_ptr(), out_off.ctypes.data, sizes.ctypes.data,
+                                             status.ctypes.data))
+            best = time.perf_counter() - t0
+        assert (status == 0).all()
+        assert np.array_equal(sizes.astype(np.int64), self.sizes.cpu().numpy()), "host path sizes differ"
+        k = self.nchunks // 2  # a chunk's bytes came back whole
+        got = h_out[k * cap: k * cap + int(sizes[k])]
+        want = self.d_out[k * cap: k * cap + int(sizes[k])].cpu()
+        assert torch.equal(got, want)
+        return {"value": round(self.n / best / 1e6, 3), "unit": "MB/s", "ms": round(best * 1e3, 1),
+                "what": "lzma_amd_encode_chunks on pinned host buffers: H2D of the input batch by batch ahead of "
+                        "the finder, D2H of every batch's output region when its launch is done, all inside the "
+                        "timed call", "host_bytes_in": self.n, "host_bytes_out": int(self.nchunks * cap)}
 
     def roofline(self):
         # encode_kernel is launched once per batch of chunks and several launches run at the
@@ -479,6 +550,31 @@ class DecodeWorkload:
         lo = int(self.offsets[self.s0].item())
         assert int(self.offsets[self.s0 + self.ns].item()) - lo == self.n
 
+    def end_to_end(self):
+        """One step through the host entry point (lzma_amd_decode_batch) on pinned host buffers:
+        compressed bytes up, raw bytes down, inside the timed call.  Warm-up call, then a timed one."""
+        N = native()
+        L = N.lib()
+        if not self.ns:
+            return None
+        h_in = self.d_in[: self.comp].cpu().pin_memory()
+        h_out = torch.empty(max(self.n, 1), dtype=torch.uint8).pin_memory()
+        in_off = self.in_off.cpu().numpy().astype(np.uint64)
+        out_off = self.out_off.cpu().numpy().astype(np.uint64)
+        sizes = np.zeros(self.ns, dtype=np.uint64)
+        status = np.zeros(self.ns, dtype=np.int32)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            N.check(L.lzma_amd_decode_batch(h_in.data_ptr(), in_off.ctypes.data, self.ns, h_out.data_ptr(),
+                                            out_off.ctypes.data, sizes.ctypes.data, status.ctypes.data))
+            best = time.perf_counter() - t0
+        assert (status == 0).all()
+        assert torch.equal(h_out[: self.n], torch.from_numpy(self.host)), "host path output differs from the raw input"
+        return {"value": round(self.n / best / 1e6, 3), "unit": "MB/s", "ms": round(best * 1e3, 1),
+                "what": "lzma_amd_decode_batch on pinned host buffers, copies inside the timed call",
+                "host_bytes_in": self.comp, "host_bytes_out": self.n}
+
     def roofline(self):
         if not self.kernel_ms:
             return None
@@ -532,7 +628,8 @@ class MfWorkload:
         from tests import synth
         self.dev = dev
         self.n = mib * MIB
-        self.host = synth.markov(self.n, cfg=1, first_block=rank * mib, threads=usable_cores())
+        self.first_block = rank * mib
+        self.host = synth.markov(self.n, cfg=1, first_block=self.first_block, threads=usable_cores())
         self.d_in = torch.from_numpy(self.host).to(dev)
         self.counts = torch.zeros(self.n, dtype=torch.int32, device=dev)
         self.offs = torch.zeros(self.n, dtype=torch.int64, device=dev)
@@ -589,6 +686,28 @@ class MfWorkload:
         open_end = (L < limit) & (L >= 4)
         a = (pos + L)[open_end]
         assert bool((data[a] != data[a - D[open_end]]).all().item())
+        self.digest_check()
+
+    def digest_check(self):
+        """Every 1 MiB block's match lists against the digests of the CPU restatement's lists
+        (tests/golden/c2_digests.json, made by tests/golden/make_c2_digests.py from the same
+        generator at the exhaustive cut value).  A list depends on its window alone, so the
+        blocks of a longer or shorter stream of the same text compare too, all but the last one
+        of the shorter of the two (where the stream's end limits the lengths)."""
+        path = Path(__file__).resolve().parent / "tests" / "golden" / "c2_digests.json"
+        self.digests_equal = None
+        if self.first_block != 0 or (self.dict, self.fb) != (1 << 20, 64) or not path.exists():
+            return
+        from tests import c2_digest
+        gold = json.loads(path.read_text())
+        mib = self.n // MIB
+        k = min(mib, gold["mib"]) - (0 if mib == gold["mib"] else 1)
+        if k <= 0:
+            return
+        got = c2_digest.digests_torch(self.counts[: k * MIB], self.offs[: k * MIB], self.pairs, MIB)
+        bad = [b for b in range(k) if f"{got[b]:016x}" != gold["digests"][b]]
+        assert not bad, f"match lists of MiB blocks {bad[:8]} (of {len(bad)}) differ from the oracle's"
+        self.digests_equal = k
 
     def roofline(self):
         ms = [t["finder_ms"] for t in self.kernel_ms[-max(1, len(self.kernel_ms) // 2):]]
@@ -618,7 +737,16 @@ class MfWorkload:
 
     def config(self):
         return {"workload": "configs[1]: BT4 match finder only, one stream of order-2 Markov text, dict 1 MiB, "
-                            "fb 64, exhaustive", "bytes_per_gpu": self.n}
+                            "fb 64, exhaustive", "bytes_per_gpu": self.n,
+                "blocks_equal_to_oracle_digests": getattr(self, "digests_equal", None)}
+
+    def dump_first_mib(self, path):
+        """Counts and pairs of the first MiB of positions, for a test to compare with the oracle."""
+        k = min(MIB, self.n)
+        c = self.counts[:k].cpu().numpy()
+        tot = int(c.sum())
+        np.savez(path, counts=c, pairs=self.pairs[: 2 * tot].cpu().numpy().reshape(-1, 2),
+                 data=self.host[: min(self.n, k + 4096)])
 
 
 class StubWorkload:
@@ -689,8 +817,10 @@ def extra_leg(name, make, budget_s):
         wl.verify()
         note(f"{name}: timed and verified")
         out = {"value": round(units / dt / 1e6, 3), "unit": "MB/s", "steps": 2, "warmup": 1,
-               "ms_per_step": round(dt / 2 * 1e3, 3), "config": wl.config(), "roofline": wl.roofline(),
-               "cpu_baseline": wl.cpu_baseline()}
+               "ms_per_step": round(dt / 2 * 1e3, 3), "config": wl.config(),
+               "roofline": with_copy_rate(wl.roofline(), dev), "cpu_baseline": wl.cpu_baseline()}
+        if hasattr(wl, "end_to_end"):
+            out["e2e"] = wl.end_to_end()
         note(f"{name}: CPU leg done")
         del wl
         torch.cuda.empty_cache()
@@ -716,6 +846,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the step through the host entry point")
+    ap.add_argument("--dump-first-mib", default=None,
+                    help="mf: save the lists of the first MiB of positions to this .npz (tests)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -757,6 +890,8 @@ def main():
         note(f"{args.warmup}+{args.steps} steps done")
     if not args.no_verify:
         wl.verify()
+    if args.dump_first_mib and args.workload == "mf" and rank == 0:
+        wl.dump_first_mib(args.dump_first_mib)
     barrier_sync(world, dev)
     if rank == 0:
         note("verified")
@@ -769,13 +904,21 @@ def main():
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak" if args.workload == "mf" else "strong", "vs_baseline": None,
             "dtype": "u8/u16/u32 integer", "data": "synthetic",
-            "config": wl.config(), "roofline": wl.roofline(),
+            "config": wl.config(), "roofline": with_copy_rate(wl.roofline(), dev),
         }
         # the CPU leg and the extra legs belong to a single-GPU run: with more ranks the
         # others would only wait for rank 0
         solo = world == 1 and dev.type == "cuda"
         line["cpu_baseline"] = wl.cpu_baseline() if (solo and not args.no_cpu_baseline) else None
         note("CPU leg done")
+        if solo and hasattr(wl, "end_to_end") and not args.no_e2e:
+            try:
+                line["e2e"] = wl.end_to_end()
+                if line["e2e"]:
+                    line["e2e_value"] = line["e2e"]["value"]
+            except Exception as e:  # must not lose the headline line
+                line["e2e"] = {"failed": f"{type(e).__name__}: {e}"}
+            note("end-to-end leg done")
         if solo and args.workload == "encode" and not args.no_extra:
             native().release_workspace()
             del wl

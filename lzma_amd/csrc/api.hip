@@ -11,6 +11,13 @@ ThreadState &tls() {
     return s;
 }
 
+HostStage &host_stage() {
+    // never destroyed on its own: at process exit the HIP runtime may already be gone
+    static thread_local HostStage *h = nullptr;
+    if (!h) h = new HostStage;
+    return *h;
+}
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -94,7 +94,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decod
     }
 }
 
+// What a decode call needs beyond the caller's buffers, kept by the calling thread between
+// calls (grow-only; lzma_amd_release_workspace frees it): allocating up to 3 GiB of literal
+// areas per call costs more than a small batch takes.
+struct DecodeWs {
+    lzh::DevBuf big, lit_small, lit_big;
+    int device = -1;
+    void release() {
+        big.release(), lit_small.release(), lit_big.release();
+        device = -1;
+    }
+};
+thread_local DecodeWs *g_dws = nullptr;
 }  // namespace
+
+void lzh::release_decode_workspace() {
+    if (g_dws) g_dws->release();
+}
 
 extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_in_off,
                                          size_t n_streams, uint8_t *d_out,
@@ -108,12 +124,20 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
         return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: null pointer argument");
     if (n_streams > 0x7FFFFFFFull)
         return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: too many streams in one call");
-    lzh::DevBuf big;  // [0] = count, [1..] = list of deferred stream indices
-    LZ_HIP(big.alloc((n_streams + 1) * sizeof(uint32_t)));
+    int dev = 0;
+    LZ_HIP(hipGetDevice(&dev));
+    if (!g_dws) g_dws = new DecodeWs;
+    if (g_dws->device != dev) {
+        g_dws->release();
+        g_dws->device = dev;
+    }
+    lzh::DevBuf &big = g_dws->big;  // [0] = count, [1..] = list of deferred stream indices
+    if (big.bytes < (n_streams + 1) * sizeof(uint32_t)) LZ_HIP(big.alloc((n_streams + 1) * sizeof(uint32_t)));
     LZ_HIP(hipMemsetAsync(big.p, 0, sizeof(uint32_t), st));
     const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, kMaxGrid);
-    lzh::DevBuf lit_small;
-    LZ_HIP(lit_small.alloc((size_t)grid * kLitSmall * sizeof(lz::prob_t)));
+    lzh::DevBuf &lit_small = g_dws->lit_small;
+    if (lit_small.bytes < (size_t)grid * kLitSmall * sizeof(lz::prob_t))
+        LZ_HIP(lit_small.alloc((size_t)grid * kLitSmall * sizeof(lz::prob_t)));
     lzh::Timer tm;
     tm.start(st);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
@@ -123,10 +147,11 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     uint32_t n_big = 0;
     LZ_HIP(hipMemcpyAsync(&n_big, big.p, sizeof n_big, hipMemcpyDeviceToHost, st));
     LZ_HIP(hipStreamSynchronize(st));
-    lzh::DevBuf scratch;
+    lzh::DevBuf &scratch = g_dws->lit_big;
     if (n_big > 0) {
         const unsigned wgs = n_big < 64 ? n_big : 64;
-        LZ_HIP(scratch.alloc((size_t)wgs * kLitBig * sizeof(lz::prob_t)));
+        if (scratch.bytes < (size_t)wgs * kLitBig * sizeof(lz::prob_t))
+            LZ_HIP(scratch.alloc((size_t)wgs * kLitBig * sizeof(lz::prob_t)));
         hipLaunchKernelGGL(decode_kernel<true>, dim3(wgs), dim3(64), 0, st, d_in, d_in_off,
                            (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
                            big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(), kLitBig, kLitSmallLog);
@@ -238,23 +263,25 @@ extern "C" int lzma_amd_decode_batch(const uint8_t *in, const uint64_t *in_off, 
     for (size_t s = 0; s < n_streams; s++)
         if (in_off[s + 1] < in_off[s] || out_off[s + 1] < out_off[s])
             return lzh::fail(LZMA_AMD_ERR_ARG, "decode_batch: offsets must be non-decreasing");
-    lzh::DevBuf d_in, d_io, d_out, d_oo, d_sz, d_st;
-    LZ_HIP(d_in.alloc(in_total));
-    LZ_HIP(d_io.alloc((n_streams + 1) * 8));
-    LZ_HIP(d_out.alloc(out_total));
-    LZ_HIP(d_oo.alloc((n_streams + 1) * 8));
-    LZ_HIP(d_sz.alloc(n_streams * 8));
-    LZ_HIP(d_st.alloc(n_streams * 4));
-    if (in_total) LZ_HIP(hipMemcpy(d_in.p, in + in_base, in_total, hipMemcpyHostToDevice));
-    LZ_HIP(hipMemcpy(d_io.p, in_off, (n_streams + 1) * 8, hipMemcpyHostToDevice));
-    LZ_HIP(hipMemcpy(d_oo.p, out_off, (n_streams + 1) * 8, hipMemcpyHostToDevice));
-    // device copies index from the batch's own base
-    int rc = lzma_amd_decode_batch_dev(d_in.as<uint8_t>() - in_base, d_io.as<uint64_t>(), n_streams,
-                                       d_out.as<uint8_t>() - out_base, d_oo.as<uint64_t>(),
-                                       d_sz.as<uint64_t>(), d_st.as<int32_t>(), nullptr);
+    // device copies of the buffers are kept by the thread between calls; everything is enqueued
+    // on one stream and waited for once
+    lzh::HostStage &H = lzh::host_stage();
+    int rc = H.prepare();
     if (rc) return rc;
-    if (out_total) LZ_HIP(hipMemcpy(out + out_base, d_out.p, out_total, hipMemcpyDeviceToHost));
-    LZ_HIP(hipMemcpy(out_sizes, d_sz.p, n_streams * 8, hipMemcpyDeviceToHost));
-    LZ_HIP(hipMemcpy(status, d_st.p, n_streams * 4, hipMemcpyDeviceToHost));
+    if ((rc = H.reserve(0, in_total)) || (rc = H.reserve(1, (n_streams + 1) * 8)) || (rc = H.reserve(2, out_total)) ||
+        (rc = H.reserve(3, (n_streams + 1) * 8)) || (rc = H.reserve(4, n_streams * 8)) || (rc = H.reserve(5, n_streams * 4)))
+        return rc;
+    if (in_total) LZ_HIP(hipMemcpyAsync(H.buf[0].p, in + in_base, in_total, hipMemcpyHostToDevice, H.stream));
+    LZ_HIP(hipMemcpyAsync(H.buf[1].p, in_off, (n_streams + 1) * 8, hipMemcpyHostToDevice, H.stream));
+    LZ_HIP(hipMemcpyAsync(H.buf[3].p, out_off, (n_streams + 1) * 8, hipMemcpyHostToDevice, H.stream));
+    // device copies index from the batch's own base
+    rc = lzma_amd_decode_batch_dev(H.buf[0].as<uint8_t>() - in_base, H.buf[1].as<uint64_t>(), n_streams,
+                                   H.buf[2].as<uint8_t>() - out_base, H.buf[3].as<uint64_t>(),
+                                   H.buf[4].as<uint64_t>(), H.buf[5].as<int32_t>(), H.stream);
+    if (rc) return rc;
+    if (out_total) LZ_HIP(hipMemcpyAsync(out + out_base, H.buf[2].p, out_total, hipMemcpyDeviceToHost, H.stream));
+    LZ_HIP(hipMemcpyAsync(out_sizes, H.buf[4].p, n_streams * 8, hipMemcpyDeviceToHost, H.stream));
+    LZ_HIP(hipMemcpyAsync(status, H.buf[5].p, n_streams * 4, hipMemcpyDeviceToHost, H.stream));
+    LZ_HIP(hipStreamSynchronize(H.stream));
     return LZMA_AMD_OK;
 }

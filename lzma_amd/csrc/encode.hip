@@ -249,6 +249,7 @@ struct Slot {
     lzh::DevBuf opt, lit;
     hipEvent_t e0 = nullptr, e1 = nullptr;  // around the batch's encode launch
     bool busy = false;
+    size_t c0 = 0, c1 = 0;                  // the chunks of the batch it holds
 };
 
 // The device gives a process four hardware queues: one for the finder and three for
@@ -330,10 +331,35 @@ int launch_encode(unsigned grid, unsigned lds, hipStream_t es, const uint8_t *da
 // one stream; the batches' encode launches go to kEncStreams other streams: one of them runs
 // beside the finder, the others start together when the finder has done its last batch (see
 // "Launch order" below), together as many chunks as the device holds at once.
+namespace {
+// Host buffers of a call that came through lzma_amd_encode_chunks: the input is copied to the
+// device batch by batch on a stream of its own, ahead of the finder (which waits for the batch
+// it is about to read, so only the first batch's copy is not hidden behind device work), and
+// every batch's output region goes back as soon as its encode launch is done.
+struct HostIo {
+    const uint8_t *in = nullptr;     // in[0] is byte in_base of the chunk offsets
+    uint64_t in_base = 0;
+    uint8_t *out = nullptr;          // out[0] is byte out_off[0] of the output offsets
+    const uint64_t *out_off = nullptr;
+    hipStream_t copy = nullptr;
+};
+int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, size_t in_total,
+                const lzma_amd_params *p, uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                int32_t *d_status, void *stream, const HostIo *hio);
+}  // namespace
+
 extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d_in_off,
                                           size_t n_chunks, size_t in_total, const lzma_amd_params *p,
                                           uint8_t *d_out, const uint64_t *d_out_off,
                                           uint64_t *d_out_sizes, int32_t *d_status, void *stream) {
+    return encode_impl(d_in, d_in_off, n_chunks, in_total, p, d_out, d_out_off, d_out_sizes, d_status, stream,
+                       nullptr);
+}
+
+namespace {
+int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, size_t in_total,
+                const lzma_amd_params *p, uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
+                int32_t *d_status, void *stream, const HostIo *hio) {
     hipStream_t st = (hipStream_t)stream;
     lzh::ThreadState &ts = lzh::tls();
     ts.ms_total = ts.ms_finder = ts.ms_coder = 0.f;
@@ -441,6 +467,24 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         grid_cap = std::max(1u, (unsigned)(lit_budget / (lit_stride * sizeof(lz::prob_t))));
     const unsigned max_grid = (unsigned)std::min<size_t>(max_chunks, grid_cap);
 
+    // host input: every batch's bytes on the copy stream, an event after each
+    std::vector<hipEvent_t> copied;
+    struct EventsGuard {
+        std::vector<hipEvent_t> &v;
+        ~EventsGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+    } events_guard{copied};
+    if (hio && hio->in) {
+        copied.resize(nbatches, nullptr);
+        for (size_t b = 0; b < nbatches; b++) {
+            const uint64_t b0 = off[cut[b]], b1 = off[cut[b + 1]];
+            LZ_HIP(hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+            if (b1 > b0)
+                LZ_HIP(hipMemcpyAsync(const_cast<uint8_t *>(d_in) + b0, hio->in + (b0 - hio->in_base), b1 - b0,
+                                      hipMemcpyHostToDevice, hio->copy));
+            LZ_HIP(hipEventRecord(copied[b], hio->copy));
+        }
+    }
+
     S.enc[0] = st;
     // whatever the caller enqueued on its stream (the inputs) comes first
     LZ_HIP(hipEventRecord(S.in_ready, st));
@@ -492,6 +536,12 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         float t = 0.f;
         if (hipEventElapsedTime(&t, sl.e0, sl.e1) == hipSuccess) ms_coder += t;
         sl.busy = false;
+        if (hio && hio->out) {  // the batch's output region goes home while other launches run
+            const uint64_t o0 = hio->out_off[sl.c0], o1 = hio->out_off[sl.c1];
+            if (o1 > o0)
+                LZ_HIP(hipMemcpyAsync(hio->out + (o0 - hio->out_off[0]), d_out + o0, o1 - o0, hipMemcpyDeviceToHost,
+                                      hio->copy));
+        }
         return LZMA_AMD_OK;
     };
     // Launch order.  A resident encode wave holds a third of a SIMD's registers, so every launch
@@ -538,6 +588,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         if (r) return bail(r);
         LZ_HIP_BAIL(hipEventRecord(sl.e1, es));
         sl.busy = true;
+        sl.c0 = cut[h.b], sl.c1 = cut[h.b + 1];
         ts.coder_launches++;
         return LZMA_AMD_OK;
     };
@@ -555,6 +606,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
         const uint64_t base = off[c0];
         const uint32_t nbytes = (uint32_t)(off[c1] - base);
         const uint32_t nchunks = (uint32_t)(c1 - c0);
+        if (!copied.empty()) LZ_HIP_BAIL(hipStreamWaitEvent(S.mf, copied[b], 0));
         t_mf[b].start(S.mf);
         // the sort temporaries live in the arena the scan is about to fill when it is large
         // enough; the first batch's sorts run before any encode launch of this call
@@ -589,6 +641,7 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     t_all.stop();
     LZ_HIP_BAIL(hipStreamSynchronize(S.mf));
     for (int i = 0; i < (int)in_flight; i++) LZ_HIP_BAIL(hipStreamSynchronize(S.enc[i]));
+    if (hio) LZ_HIP_BAIL(hipStreamSynchronize(hio->copy));
 #undef LZ_HIP_BAIL
     float ms_finder = 0.f;
     for (auto &t : t_mf) ms_finder += t.ms();
@@ -597,10 +650,13 @@ extern "C" int lzma_amd_encode_chunks_dev(const uint8_t *d_in, const uint64_t *d
     ts.ms_total = t_all.ms();
     return LZMA_AMD_OK;
 }
+}  // namespace
 
 extern "C" void lzma_amd_release_workspace(void) {
     if (g_ws) g_ws->release();
     lzh::release_finder_workspace();
+    lzh::release_decode_workspace();
+    lzh::host_stage().release();
 }
 
 extern "C" int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off, size_t n_chunks,
@@ -616,22 +672,28 @@ extern "C" int lzma_amd_encode_chunks(const uint8_t *in, const uint64_t *in_off,
             return lzh::fail(LZMA_AMD_ERR_ARG, "encode_chunks: offsets must be non-decreasing");
     const uint64_t in_base = in_off[0], in_total = in_off[n_chunks] - in_base;
     const uint64_t out_base = out_off[0], out_total = out_off[n_chunks] - out_base;
-    lzh::DevBuf d_in, d_io, d_out, d_oo, d_sz, d_st;
-    LZ_HIP(d_in.alloc(in_total));
-    LZ_HIP(d_io.alloc((n_chunks + 1) * 8));
-    LZ_HIP(d_out.alloc(out_total));
-    LZ_HIP(d_oo.alloc((n_chunks + 1) * 8));
-    LZ_HIP(d_sz.alloc(n_chunks * 8));
-    LZ_HIP(d_st.alloc(n_chunks * 4));
-    if (in_total) LZ_HIP(hipMemcpy(d_in.p, in + in_base, in_total, hipMemcpyHostToDevice));
-    LZ_HIP(hipMemcpy(d_io.p, in_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
-    LZ_HIP(hipMemcpy(d_oo.p, out_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
-    rc = lzma_amd_encode_chunks_dev(d_in.as<uint8_t>() - in_base, d_io.as<uint64_t>(), n_chunks,
-                                    in_base + in_total, p, d_out.as<uint8_t>() - out_base, d_oo.as<uint64_t>(),
-                                    d_sz.as<uint64_t>(), d_st.as<int32_t>(), nullptr);
-    if (rc) return rc;
-    if (out_total) LZ_HIP(hipMemcpy(out + out_base, d_out.p, out_total, hipMemcpyDeviceToHost));
-    LZ_HIP(hipMemcpy(out_sizes, d_sz.p, n_chunks * 8, hipMemcpyDeviceToHost));
-    LZ_HIP(hipMemcpy(status, d_st.p, n_chunks * 4, hipMemcpyDeviceToHost));
+    // Device copies of the buffers are kept by the thread between calls; the bytes travel on a
+    // stream of their own beside the kernels (HostIo).  Pinned caller buffers (hipHostMalloc /
+    // hipHostRegister) make those copies truly asynchronous; pageable ones work, more slowly.
+    lzh::HostStage &H = lzh::host_stage();
+    if ((rc = H.prepare())) return rc;
+    if ((rc = H.reserve(0, in_total)) || (rc = H.reserve(1, (n_chunks + 1) * 8)) || (rc = H.reserve(2, out_total)) ||
+        (rc = H.reserve(3, (n_chunks + 1) * 8)) || (rc = H.reserve(4, n_chunks * 8)) || (rc = H.reserve(5, n_chunks * 4)))
+        return rc;
+    LZ_HIP(hipMemcpyAsync(H.buf[1].p, in_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice, H.stream));
+    LZ_HIP(hipMemcpyAsync(H.buf[3].p, out_off, (n_chunks + 1) * 8, hipMemcpyHostToDevice, H.stream));
+    LZ_HIP(hipStreamSynchronize(H.stream));
+    HostIo hio;
+    hio.in = in + in_base, hio.in_base = in_base, hio.out = out + out_base, hio.out_off = out_off, hio.copy = H.stream;
+    rc = encode_impl(H.buf[0].as<uint8_t>() - in_base, H.buf[1].as<uint64_t>(), n_chunks, in_base + in_total, p,
+                     H.buf[2].as<uint8_t>() - out_base, H.buf[3].as<uint64_t>(), H.buf[4].as<uint64_t>(),
+                     H.buf[5].as<int32_t>(), nullptr, &hio);
+    if (rc) {
+        (void)hipDeviceSynchronize();
+        return rc;
+    }
+    LZ_HIP(hipMemcpyAsync(out_sizes, H.buf[4].p, n_chunks * 8, hipMemcpyDeviceToHost, H.stream));
+    LZ_HIP(hipMemcpyAsync(status, H.buf[5].p, n_chunks * 4, hipMemcpyDeviceToHost, H.stream));
+    LZ_HIP(hipStreamSynchronize(H.stream));
     return LZMA_AMD_OK;
 }

@@ -17,6 +17,7 @@ struct ThreadState {
     int coder_launches, coop_launches;
 };
 ThreadState &tls();
+void release_decode_workspace();  // decode.hip: what the calling thread's decode calls keep
 int noalloc_prepare();  // decode.hip: address of the no-allocation entry point's device array
 int fail(int code, const char *fmt, ...);
 
@@ -50,6 +51,37 @@ struct DevBuf {
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// Device-side copies of a host call's buffers, kept by the calling thread from one call to the
+// next (grow-only; lzma_amd_release_workspace frees them): the host entry points allocate
+// nothing once they have seen their largest batch.
+struct HostStage {
+    static constexpr int kBufs = 6;
+    DevBuf buf[kBufs];
+    hipStream_t stream = nullptr;
+    int device = -1;
+    int prepare() {
+        int dev = 0;
+        LZ_HIP(hipGetDevice(&dev));
+        if (dev != device) {
+            release();
+            device = dev;
+            LZ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
+        return LZMA_AMD_OK;
+    }
+    int reserve(int i, size_t bytes) {
+        if (buf[i].bytes < bytes || !buf[i].p) LZ_HIP(buf[i].alloc(bytes + bytes / 8));
+        return LZMA_AMD_OK;
+    }
+    void release() {
+        for (auto &b : buf) b.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        device = -1;
+    }
+};
+HostStage &host_stage();  // the calling thread's
 
 // Pair of events around a region of one stream.
 struct Timer {

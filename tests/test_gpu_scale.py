@@ -216,3 +216,41 @@ def test_bench_two_ranks_on_one_gpu():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["chunks_total"] == 65 and line["config"]["chunks_this_rank"] == 33
+
+
+def _bench_line(args, timeout):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py"] + args, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+
+
+@pytest.mark.timeout(600)
+def test_match_finder_benchmark_stream_equals_oracle_digests():
+    """The match-finder benchmark at its full size (256 MiB, one stream, dictionary 1 MiB): the
+    lists of every 1 MiB block have the digest of the oracle's lists at the exhaustive cut value
+    (tests/golden/c2_digests.json; bench.py's verification compares all 256 and fails otherwise)."""
+    line = _bench_line(["--workload", "mf", "--mib", "256", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], 500)
+    assert line["config"]["blocks_equal_to_oracle_digests"] == 256
+
+
+@pytest.mark.timeout(900)
+def test_match_finder_beyond_two_to_the_thirty_positions(tmp_path):
+    """One finder call over more than 2^30 positions (the tables' rank words then carry a flag
+    instead of a group-size class): the properties of bench.py's verification, the digests of the
+    first 255 MiB blocks (same text as the benchmark stream), and the first MiB of positions pair
+    for pair against the oracle."""
+    dump = tmp_path / "first_mib.npz"
+    line = _bench_line(["--workload", "mf", "--mib", "1040", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--dump-first-mib", str(dump)], 800)
+    assert line["config"]["bytes_per_gpu"] == 1040 * MIB
+    assert line["config"]["blocks_equal_to_oracle_digests"] == 255
+    z = np.load(dump)
+    c_ref, p_ref = O.bt4_matches(z["data"].tobytes(), 1 << 20, 64, 1 << 30)
+    tot = int(c_ref[:MIB].sum())
+    assert np.array_equal(z["counts"], c_ref[:MIB])
+    assert np.array_equal(z["pairs"].astype(np.uint32), p_ref[:tot])
