@@ -911,7 +911,9 @@ def main():
         solo = world == 1 and dev.type == "cuda"
         line["cpu_baseline"] = wl.cpu_baseline() if (solo and not args.no_cpu_baseline) else None
         note("CPU leg done")
-        if solo and hasattr(wl, "end_to_end") and not args.no_e2e:
+        if solo and hasattr(wl, "end_to_end") and not args.no_e2e and dt / max(args.steps, 1) > 40.0:
+            line["e2e"] = {"skipped": "a step takes longer than 40 s: the leg's two calls would double the run"}
+        elif solo and hasattr(wl, "end_to_end") and not args.no_e2e:
             try:
                 line["e2e"] = wl.end_to_end()
                 if line["e2e"]:

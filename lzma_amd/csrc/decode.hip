@@ -18,6 +18,7 @@
 // Roofline class: HBM-bound in principle (reads C compressed bytes, writes N raw
 // bytes per stream), instruction-issue-bound in practice.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "host_util.hpp"
@@ -43,14 +44,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decod
     const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off, uint64_t n_streams,
     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     uint64_t *__restrict__ out_sizes, int32_t *__restrict__ status, uint32_t *big_count,
-    uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride, uint32_t lit_small_log) {
+    uint32_t *big_list, lz::prob_t *lit_scratch, uint64_t lit_scratch_stride, uint32_t lit_small_log,
+    uint32_t *ticket) {
     __shared__ __align__(16) lz::prob_t s_probs[lz::kNumBaseProbs];
     const uint32_t lane = threadIdx.x;
     lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_scratch_stride;
 
+    // ticket != nullptr: the workgroups (as many as are resident) draw the streams from a
+    // counter, so that streams of very different length still keep every workgroup busy while
+    // the literal areas in use are those of the resident workgroups only; else workgroup b
+    // takes streams b, b + gridDim, ...
     uint64_t first = blockIdx.x, step = gridDim.x;
     uint64_t count = BIG ? (uint64_t)*big_count : n_streams;
-    for (uint64_t it = first; it < count; it += step) {
+    for (uint64_t it = first;; it += step) {
+        if (ticket) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(ticket, 1u);
+            it = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        }
+        if (it >= count) break;
         const uint64_t s = BIG ? (uint64_t)big_list[it] : it;
         const uint64_t ib = in_off[s], ie = in_off[s + 1];
         const uint64_t ob = out_off[s], oe = out_off[s + 1];
@@ -100,9 +112,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void decod
 struct DecodeWs {
     lzh::DevBuf big, lit_small, lit_big;
     int device = -1;
+    unsigned resident = 0;  // workgroups of the first launch the device holds at once
     void release() {
         big.release(), lit_small.release(), lit_big.release();
         device = -1;
+        resident = 0;
     }
 };
 thread_local DecodeWs *g_dws = nullptr;
@@ -132,9 +146,22 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
         g_dws->device = dev;
     }
     lzh::DevBuf &big = g_dws->big;  // [0] = count, [1..] = list of deferred stream indices
-    if (big.bytes < (n_streams + 1) * sizeof(uint32_t)) LZ_HIP(big.alloc((n_streams + 1) * sizeof(uint32_t)));
-    LZ_HIP(hipMemsetAsync(big.p, 0, sizeof(uint32_t), st));
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, kMaxGrid);
+    // [0] = count of deferred streams, [1] = the counter the streams are drawn from, [2..] = list
+    if (big.bytes < (n_streams + 2) * sizeof(uint32_t)) LZ_HIP(big.alloc((n_streams + 2) * sizeof(uint32_t)));
+    LZ_HIP(hipMemsetAsync(big.p, 0, 2 * sizeof(uint32_t), st));
+    // as many workgroups as the device holds at once: each owns one literal area, reused stream
+    // after stream, so the models in use stay inside the caches (the areas of a grid with one
+    // workgroup per stream were written back to memory long after their streams had ended)
+    if (g_dws->resident == 0) {
+        hipDeviceProp_t pr;
+        LZ_HIP(hipGetDeviceProperties(&pr, dev));
+        int per_cu = 0;
+        LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_kernel<false>, 64, 0));
+        g_dws->resident = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, pr.multiProcessorCount);
+    }
+    unsigned want = g_dws->resident;
+    if (const char *e = getenv("LZMA_AMD_DECODE_GRID")) want = (unsigned)std::max(1, atoi(e));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, std::min<uint64_t>(want, kMaxGrid));
     lzh::DevBuf &lit_small = g_dws->lit_small;
     if (lit_small.bytes < (size_t)grid * kLitSmall * sizeof(lz::prob_t))
         LZ_HIP(lit_small.alloc((size_t)grid * kLitSmall * sizeof(lz::prob_t)));
@@ -142,7 +169,8 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
     tm.start(st);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
                        (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big.as<uint32_t>(),
-                       big.as<uint32_t>() + 1, lit_small.as<lz::prob_t>(), kLitSmall, kLitSmallLog);
+                       big.as<uint32_t>() + 2, lit_small.as<lz::prob_t>(), kLitSmall, kLitSmallLog,
+                       big.as<uint32_t>() + 1);
     LZ_HIP(hipGetLastError());
     uint32_t n_big = 0;
     LZ_HIP(hipMemcpyAsync(&n_big, big.p, sizeof n_big, hipMemcpyDeviceToHost, st));
@@ -154,7 +182,8 @@ extern "C" int lzma_amd_decode_batch_dev(const uint8_t *d_in, const uint64_t *d_
             LZ_HIP(scratch.alloc((size_t)wgs * kLitBig * sizeof(lz::prob_t)));
         hipLaunchKernelGGL(decode_kernel<true>, dim3(wgs), dim3(64), 0, st, d_in, d_in_off,
                            (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status,
-                           big.as<uint32_t>(), big.as<uint32_t>() + 1, scratch.as<lz::prob_t>(), kLitBig, kLitSmallLog);
+                           big.as<uint32_t>(), big.as<uint32_t>() + 2, scratch.as<lz::prob_t>(), kLitBig, kLitSmallLog,
+                           (uint32_t *)nullptr);
         LZ_HIP(hipGetLastError());
     }
     tm.stop();
@@ -239,14 +268,15 @@ extern "C" int lzma_amd_decode_batch_dev_noalloc(const uint8_t *d_in, const uint
     const unsigned grid = (unsigned)std::min<uint64_t>(n_streams, kNaGrid);
     hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, d_in_off,
                        (uint64_t)n_streams, d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small,
-                       kNaLitModels, kNaLitLog);
+                       kNaLitModels, kNaLitLog, (uint32_t *)nullptr);
     LZ_HIP(hipGetLastError());
     // the second launch reads the count on the device: nine workgroups with full-size areas (the
     // first launch's areas, free again, and the one behind them) share the deferred streams
     // (none: they return at once)
     (void)lit_big;  // = lit_small + 8 full-size areas
     hipLaunchKernelGGL(decode_kernel<true>, dim3(kNaBigGrid), dim3(64), 0, st, d_in, d_in_off, (uint64_t)n_streams,
-                       d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small, kLitBig, kNaLitLog);
+                       d_out, d_out_off, d_out_sizes, d_status, big, big + 64, lit_small, kLitBig, kNaLitLog,
+                       (uint32_t *)nullptr);
     LZ_HIP(hipGetLastError());
     lzh::tls().coder_launches = 2;
     return LZMA_AMD_OK;  // results are there when the stream has run: the caller waits for it
