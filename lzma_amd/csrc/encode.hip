@@ -57,33 +57,15 @@ struct MfFunctor {
             out[k] = w;
         }
     }
-    // lane 8 + j of a list of up to 56 pairs also keeps pair j in registers (l, d): the round
-    // reads its tasks from there without a trip through LDS
-#if !defined(__HIP_DEVICE_COMPILE__)
-    // (the host pass only needs the call in lz::Encoder to type-check)
-    __device__ uint32_t operator()(uint32_t, LZ_LDS uint32_t *, uint32_t *, uint32_t *) { return 0; }
-#else
-    __device__ uint32_t operator()(uint32_t pos, LZ_LDS uint32_t *out, uint32_t &l, uint32_t &d) {
+    __device__ uint32_t operator()(uint32_t pos, LZ_LDS uint32_t *out) {
         const bool hit = pos == pf_pos;
         const uint64_t m = uni64(hit ? pf_meta : meta[job_start + pos]);
         const uint32_t c = lz::mf_meta_count(m);
-        if (PACKED && c <= 56) {
-            uint32_t w = pf_word;
-            if (!hit) w = (lane >= 8 && lane - 8 < c) ? arena[first(m) + lane - 8] : 0;
-            if (lane >= 8 && lane - 8 < c) {
-                l = lz::mf_pack_len(w), d = lz::mf_pack_dist(w);
-                out[2 * (lane - 8)] = l;
-                out[2 * (lane - 8) + 1] = d;
-            }
-        } else if (hit && words(c) <= 64) {
+        if (hit && words(c) <= 64) {
             if (lane < words(c)) put(out, lane, pf_word);
         } else {
             const uint32_t *src = arena + first(m);
             for (uint32_t k = lane; k < words(c); k += 64) put(out, k, src[k]);
-        }
-        if (!PACKED && c <= 56) {  // two-word pairs: from the array just written
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (lane >= 8 && lane - 8 < c) l = out[2 * (lane - 8)], d = out[2 * (lane - 8) + 1];
         }
         uint32_t g1 = job_start + pos + STEP, g2 = job_start + pos + 2 * STEP;
         if (g1 >= n_total) g1 = n_total - 1;
@@ -91,19 +73,13 @@ struct MfFunctor {
         const uint64_t m1 = uni64(hit ? pf_meta2 : meta[g1]);
         const uint32_t c1 = lz::mf_meta_count(m1);
         uint32_t w = 0;
-        if (PACKED) {  // pair j of the next list for lane 8 + j
-            if (c1 <= 56 && lane >= 8 && lane - 8 < c1) w = arena[first(m1) + lane - 8];
-            if (c1 > 56 && c1 <= 64 && lane < c1) w = arena[first(m1) + lane];
-        } else if (words(c1) <= 64 && lane < words(c1)) {
-            w = arena[first(m1) + lane];
-        }
+        if (words(c1) <= 64 && lane < words(c1)) w = arena[first(m1) + lane];
         pf_word = w;
         pf_meta = m1;
         pf_meta2 = meta[g2];
         pf_pos = pos + STEP;
         return c;
     }
-#endif
 };
 
 struct LdsLayout {

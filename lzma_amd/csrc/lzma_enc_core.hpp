@@ -466,28 +466,14 @@ struct Encoder {
     LZ_HD uint32_t up1(uint32_t p) const { return U(price1(p)); }
     // Window bookkeeping when cur advances to c (by one): the entry that enters the
     // window is fetched from HBM if anything was ever written that far out.
-    // The fetch is issued here and lands in the window only when win_land() is called, before
-    // the first access to the entries ahead of cur: what the position does in between (its
-    // match list, path, prices and round) hides the memory round trip.
-    Rec pend_rec;
-    uint32_t pend_slot;  // window slot waiting for pend_rec, kNoSlot if none
-    static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
     LZ_HD void win_advance(uint32_t c) {
         wcur = c;
-        pend_slot = kNoSlot;
         const uint32_t lo = c > kRecBack ? c - kRecBack : 0;
         if (lo != wlo) {
             wlo = lo;
             const uint32_t e = lo + kWinSpan - 1;
-            if (e <= far_hi && e < kNumOpts) {
-                if (one()) pend_rec = opt_g[e].rec;
-                pend_slot = e & (kRecWin - 1);
-            }
+            if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
         }
-    }
-    LZ_HD void win_land() {
-        if (pend_slot != kNoSlot && one()) o_rec[pend_slot] = pend_rec;
-        pend_slot = kNoSlot;
     }
     // COOP: the window of position c is set when the wave turns to c (win_set) and the entry it
     // gains is fetched when the apply phases of all earlier positions are done (win_enter)
@@ -767,13 +753,9 @@ struct Encoder {
         return r < limit ? r : limit;
     }
 
-    // The list of the position just asked for, one pair per lane (lane 8 + j: pair j), as the
-    // round wants it; valid for lists of up to kLanes - 8 pairs (longer ones are read from mdist).
-    LZ_LANEVAR(pr_len);
-    LZ_LANEVAR(pr_dist);
     LZ_HD uint32_t read_match_distances() {  // lzma_encoder.go:274-285
         uint32_t res = 0;
-        dist_pairs = 2 * U(mf(mfpos, mdist, pr_len, pr_dist));
+        dist_pairs = 2 * U(mf(mfpos, mdist));
         mfpos++;
         if (dist_pairs > 0) {
             res = U(mdist[dist_pairs - 2]);
@@ -1022,8 +1004,7 @@ struct Encoder {
         uint32_t a_off, dist, lim1, lim2, lt_pair;
     };
     LZ_HD RoundTask round_task(uint32_t L, uint32_t jbase, bool do_rest, uint32_t npairs, uint32_t r0, uint32_t r1,
-                               uint32_t r2, uint32_t r3, uint32_t av, uint32_t avail_full, uint32_t lane_len,
-                               uint32_t lane_dist) const {
+                               uint32_t r2, uint32_t r3, uint32_t av, uint32_t avail_full) const {
         const uint32_t fb = ep.fb;
         const bool first = jbase == 0;
         const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
@@ -1038,10 +1019,7 @@ struct Encoder {
             t.dist = r0;
             if (do_rest) t.lim2 = avail_full - 1 < fb ? avail_full - 1 : fb;
         } else if (t.is_pair) {
-            if (npairs <= kLanes - 8)
-                t.lt_pair = lane_len, t.dist = lane_dist;
-            else
-                t.lt_pair = mdist[2 * j], t.dist = mdist[2 * j + 1];
+            t.lt_pair = mdist[2 * j], t.dist = mdist[2 * j + 1];
             t.a_off += t.lt_pair;
             if (t.lt_pair < avail_full) t.lim2 = avail_full - 1 - t.lt_pair < fb ? avail_full - 1 - t.lt_pair : fb;
         }
@@ -1379,9 +1357,6 @@ struct Encoder {
                 while (new_len > U(mdist[2 * j])) j++;
                 if (one()) mdist[2 * j] = new_len;
                 npairs = j + 1;
-                LZ_LANES_BEGIN(L)
-                if (L == 8 + j) LZ_LV(pr_len, L) = new_len;
-                LZ_LANES_END
             }
             // ---- state and reps of the path that reaches cur (:525-597).  The entry E the
             // path comes from always holds the reps to permute (for a literal or short rep it
@@ -1502,8 +1477,7 @@ struct Encoder {
             for (uint32_t jbase = 0; jbase == 0 || jbase < npairs; jbase += kLanes - 8) {
                 const bool first = jbase == 0;
                 const uint32_t j = jbase + L - 8;  // pair index of lanes >= 8
-                const RoundTask t = round_task(L, jbase, do_rest, npairs, r0, r1, r2, r3, av, avail_full,
-                                               LZ_LV(pr_len, L), LZ_LV(pr_dist, L));
+                const RoundTask t = round_task(L, jbase, do_rest, npairs, r0, r1, r2, r3, av, avail_full);
                 const bool is_rep = t.is_rep, is_lit = t.is_lit, active = t.active;
                 const uint32_t a_off = t.a_off, dist = t.dist, lim1 = t.lim1, lt_pair = t.lt_pair;
                 uint32_t lim2 = t.lim2, rprp = 0;
@@ -1618,7 +1592,6 @@ struct Encoder {
                 const NextUpd u = merge_next(nxr, cur, cur_and1, short_rep, match_byte == cur_byte);
                 if (u.changed) u_set_pbp(cur + 1, u.price, u.back, u.pp);
                 next_is_char = u.next_is_char;
-                win_land();
                 if (!do_rest) continue;
             } else {
                 // is this position parsed at all?  Known when A(cur - 1) is done.

@@ -78,10 +78,9 @@ struct ChainMF {
 };
 struct ChainMFRef {
     const ChainMF *m;
-    uint32_t operator()(uint32_t pos, uint32_t *out, uint32_t *lane_len, uint32_t *lane_dist) const {
+    uint32_t operator()(uint32_t pos, uint32_t *out) const {
         uint32_t c = m->counts[pos];
         memcpy(out, m->pairs.data() + m->offs[pos], c * 8);
-        for (uint32_t j = 0; j < c && j < 56; j++) lane_len[8 + j] = out[2 * j], lane_dist[8 + j] = out[2 * j + 1];
         return c;
     }
 };
