@@ -85,8 +85,11 @@ struct MfFunctor {
 struct LdsLayout {
     uint32_t probs, prices, pp, opt, small, total;  // byte offsets
     uint32_t sync, own1;                            // cooperative workgroups only
+    uint32_t lit;                                   // ... with the literal models in LDS
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb, bool coop) {
+// waves > 1: a cooperative workgroup of that many waves, which keeps its literal models
+// (lit_models of them) in LDS
+__host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb, uint32_t waves = 1, uint32_t lit_models = 0) {
     LdsLayout l;
     uint32_t nprobs = lz::kNumBaseProbs;
     l.probs = 0;
@@ -96,20 +99,23 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t pb, uint32_t fb, bool c
     l.small = l.opt + (lz::kRecWin + lz::kBksWin) * 16;
     l.total = l.small + lz::enc_small_words(fb, pb) * 4;
     l.sync = l.own1 = l.total;
-    if (coop) {  // the block the two waves synchronise through, and the second wave's match list and records
+    if (waves > 1) {  // the block the waves synchronise through, and the other waves' match lists and records
         l.own1 = l.sync + lz::SY_WORDS * 4;
-        l.total = l.own1 + (lz::la_words(fb) + lz::mdist_words(fb)) * 4;
+        l.total = l.own1 + (waves - 1) * (lz::la_words(fb) + lz::mdist_words(fb)) * 4;
     }
+    l.lit = (l.total + 15) & ~15u;
+    if (lit_models) l.total = l.lit + lit_models * 2;
     return l;
 }
 
 // Chunks [c0, c0 + nchunks) of the call; their bytes start at data offset
 // in_off[c] - base inside t.data.
-// COOP: two waves per chunk (workgroups of 128 threads), for launches that leave wave slots
-// free: the parse loop of a chunk runs on both (lz::Encoder::parse_loop), everything else on
-// the first.
-template <bool PACKED, bool COOP>
-__global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
+// NW > 1: that many waves per chunk (workgroups of 64 * NW threads), for launches that leave
+// wave slots free: the parse loop of a chunk runs on all of them (lz::Encoder::parse_loop),
+// everything else on the first.  Their literal models live in LDS as well: a device that is not
+// full has the LDS to spare, and every literal priced or coded saves a trip to memory.
+template <bool PACKED, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void encode_kernel(const uint8_t *__restrict__ data, uint32_t data_n,
                                                     const uint64_t *__restrict__ mf_meta,
                                                     const uint32_t *__restrict__ mf_arena,
                                                     const uint64_t *__restrict__ in_off,
@@ -123,10 +129,12 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
     // A chunk's wave is one long dependent chain; the finder's waves sharing its SIMD are many
     // and interchangeable.  Issue priority to the chain: the finder fills the slots it leaves.
     __builtin_amdgcn_s_setprio(3);
-    constexpr uint32_t kThreads = COOP ? 128 : 64;
+    constexpr bool COOP = NW > 1, LITLDS = NW > 1;
+    constexpr uint32_t kThreads = 64 * NW;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = COOP ? lz::U(threadIdx.x >> 6) : 0;
-    const LdsLayout L = lds_layout(ep.pb, ep.fb, COOP);
+    const uint32_t lit_n = 0x300u << (ep.lc + ep.lp);
+    const LdsLayout L = lds_layout(ep.pb, ep.fb, NW, LITLDS ? lit_n : 0u);
     LZ_LDS uint8_t *sm = (LZ_LDS uint8_t *)smem;
     LZ_LDS lz::prob_t *probs = (LZ_LDS lz::prob_t *)(sm + L.probs);
     LZ_LDS uint16_t *prices = (LZ_LDS uint16_t *)(sm + L.prices);
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
     LZ_LDS uint32_t *optl = (LZ_LDS uint32_t *)(sm + L.opt);
     LZ_LDS uint32_t *small = (LZ_LDS uint32_t *)(sm + L.small);
     LZ_LDS uint32_t *sync = (LZ_LDS uint32_t *)(sm + L.sync);
-    const uint32_t lit_n = 0x300u << (ep.lc + ep.lp);
+    typedef typename std::conditional<LITLDS, LZ_LDS lz::prob_t *, lz::prob_t *>::type LitPtr;
     lz::build_prob_prices((uint16_t *)pp, threadIdx.x, kThreads);
 
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -150,12 +158,16 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lz::kNumBaseProbs; i += kThreads) probs[i] = lz::kProbInit;
-        lz::prob_t *lit = lit_scratch + (uint64_t)blockIdx.x * lit_stride;
+        LitPtr lit;
+        if constexpr (LITLDS)
+            lit = (LZ_LDS lz::prob_t *)(sm + L.lit);
+        else
+            lit = lit_scratch + (uint64_t)blockIdx.x * lit_stride;
         for (uint32_t i = threadIdx.x; i < lit_n; i += kThreads) lit[i] = lz::kProbInit;
         if (COOP && threadIdx.x < lz::SY_WORDS) sync[threadIdx.x] = 0;
         __syncthreads();
 
-        lz::Encoder<MfFunctor<PACKED, COOP ? 2 : 1>, lz::prob_t *, COOP> e;
+        lz::Encoder<MfFunctor<PACKED, NW>, LitPtr, NW> e;
         e.data = data + jb;
         e.n = je - jb;
         e.readable = data_n - jb;
@@ -170,17 +182,17 @@ __global__ __launch_bounds__(COOP ? 128 : 64) void encode_kernel(const uint8_t *
         e.lane_id = lane;
         e.out = out + ob + lz::kHeaderSize;
         e.out_cap = oe - ob - lz::kHeaderSize;
-        e.mf = MfFunctor<PACKED, COOP ? 2 : 1>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
+        e.mf = MfFunctor<PACKED, NW>{mf_meta, mf_arena, jb, lane, data_n, lz::kNone, 0, 0, 0};
         e.ep = ep;
 #if defined(LZ_PROFILE)
         for (int i = 0; i < 16; i++) e.prof[i] = 0;
         e.prof_last = __builtin_readcyclecounter();
 #endif
         if (COOP && wave != 0) {
-            e.helper_run(small, (LZ_LDS uint32_t *)(sm + L.own1));
+            e.helper_run(small, (LZ_LDS uint32_t *)(sm + L.own1) + (wave - 1) * (lz::la_words(ep.fb) + lz::mdist_words(ep.fb)), wave);
 #if defined(LZ_PROFILE)
             if (lane == 0 && blockIdx.x == 0)
-                printf("PROF wave 1: mf %llu | wait-S %llu | path %llu | prices %llu | round-loads %llu | round %llu | lit %llu | wait-A %llu | wait-M %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | other %llu | idle %llu\n",
+                printf("PROF helper: mf %llu | wait-S %llu | path %llu | prices %llu | round-loads %llu | round %llu | lit %llu | wait-A %llu | wait-M %llu | litcont %llu | ends %llu | apply %llu | loopctl %llu | other %llu | idle %llu\n",
                        (unsigned long long)e.prof[0], (unsigned long long)e.prof[12], (unsigned long long)e.prof[8], (unsigned long long)e.prof[1],
                        (unsigned long long)e.prof[11], (unsigned long long)e.prof[2], (unsigned long long)e.prof[9], (unsigned long long)e.prof[13],
                        (unsigned long long)e.prof[14], (unsigned long long)e.prof[10], (unsigned long long)e.prof[3], (unsigned long long)e.prof[4],
@@ -313,12 +325,12 @@ struct Workspace {
 // never destroyed on its own: at process exit the HIP runtime may already be gone
 thread_local Workspace *g_ws = nullptr;
 
-template <bool PACKED, bool COOP>
+template <bool PACKED, uint32_t NW>
 int launch_encode(unsigned grid, unsigned lds, hipStream_t es, const uint8_t *data, uint32_t nbytes,
                   const lzh::MfResult &res, const uint64_t *d_in_off, uint64_t base, uint64_t c0, uint32_t nchunks,
                   const lz::EncParams &ep, uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_sizes,
                   int32_t *d_status, lz::OptG *opt, lz::prob_t *lit, uint64_t lit_stride) {
-    hipLaunchKernelGGL((encode_kernel<PACKED, COOP>), dim3(grid), dim3(COOP ? 128 : 64), lds, es, data, nbytes, res.d_meta(),
+    hipLaunchKernelGGL((encode_kernel<PACKED, NW>), dim3(grid), dim3(64 * NW), lds, es, data, nbytes, res.d_meta(),
                        res.d_arena(), d_in_off, base, c0, nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
                        opt, lit, lit_stride);
     LZ_HIP(hipGetLastError());
@@ -384,7 +396,12 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
                          (unsigned long long)off[n_chunks], in_total);
     lz::EncParams ep = {p->fb, p->lc, p->lp, p->pb, 1u << p->dict_log, p->dict_log * 2,
                         (uint32_t)(p->eos != 0)};
-    const LdsLayout L = lds_layout(p->pb, p->fb, false), LC = lds_layout(p->pb, p->fb, true);
+    const LdsLayout L = lds_layout(p->pb, p->fb);
+    // cooperative workgroups keep their literal models in LDS: coders of up to 0x300 << 4 models
+    // (24 KiB); chunks with larger ones are encoded by one wave each
+    const bool coop_ok = p->lc + p->lp <= 4;
+    const LdsLayout L2 = lds_layout(p->pb, p->fb, 2, 0x300u << (p->lc + p->lp));
+    const LdsLayout L3 = lds_layout(p->pb, p->fb, 3, 0x300u << (p->lc + p->lp));
     const uint64_t lit_stride = 0x300ull << (p->lc + p->lp);
     const bool packed = lz::mf_can_pack(ep.dict_size);
 
@@ -405,8 +422,8 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
     unsigned per_cu = std::min(kWavesPerSimd * S.shape.simds_per_cu, S.shape.lds_per_cu / lds_per_wg);
     {
         int api = 0;
-        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, false>, 64, L.total)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, false>, 64, L.total);
+        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, 1>, 64, L.total)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, 1>, 64, L.total);
         if (e == hipSuccess && api > 0) per_cu = std::min(per_cu, (unsigned)api);
     }
     unsigned resident = S.shape.cus * std::max(1u, per_cu);
@@ -561,8 +578,16 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
     std::vector<Held> held;
     int co_run = 1;
     if (const char *e = getenv("LZMA_AMD_CO_RUN")) co_run = std::max(0, atoi(e));
-    int coop_mode = -1;  // -1: by the number of chunks left, 0: never, 1: always
+    int coop_mode = -1;  // -1: by the number of chunks, 0: one wave per chunk, 1 or 2: two waves, 3: three
     if (const char *e = getenv("LZMA_AMD_COOP")) coop_mode = atoi(e);
+    // workgroups of three waves the device holds at once
+    unsigned resident3 = 0;
+    if (coop_ok) {
+        int api = 0;
+        hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, 3>, 192, L3.total)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, 3>, 192, L3.total);
+        if (e == hipSuccess && api > 0) resident3 = (unsigned)api * S.shape.cus;
+    }
     auto running = [&]() -> int {
         int n = 0;
         for (int i = 0; i < nslots; i++)
@@ -574,14 +599,26 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
         hipStream_t es = S.enc[h.b % in_flight];
         const unsigned grid = std::min(h.nchunks, grid_cap);
         LZ_HIP_BAIL(hipEventRecord(sl.e0, es));
-        // Two waves per chunk when the call has so few chunks that half of the wave slots
-        // would stay empty.  (Not for the last launches of a larger call: they run beside
-        // earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
+        // Several waves per chunk when the call has so few chunks that wave slots would stay empty:
+        // three if every chunk can have a resident workgroup of three, else two if half of the
+        // slots would be empty otherwise.  (Not for the last launches of a larger call: they run
+        // beside earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
         // in sum than one does -- measured on 4096 chunks: 18.8 s against 15.8 s.)
-        const bool coop = coop_mode == 1 || (coop_mode < 0 && 2 * (uint64_t)n_chunks <= resident);
-        auto fn = packed ? (coop ? launch_encode<true, true> : launch_encode<true, false>)
-                         : (coop ? launch_encode<false, true> : launch_encode<false, false>);
-        int r = fn(grid, coop ? LC.total : L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,
+        unsigned nw = 1;
+        if (coop_ok && coop_mode != 0) {
+            if (coop_mode == 2 || coop_mode == 3)
+                nw = (unsigned)coop_mode;
+            else if (coop_mode == 1)
+                nw = 2;
+            else if (n_chunks <= resident3)
+                nw = 3;
+            else if (2 * (uint64_t)n_chunks <= resident)
+                nw = 2;
+        }
+        const bool coop = nw > 1;
+        auto fn = packed ? (nw == 3 ? launch_encode<true, 3> : nw == 2 ? launch_encode<true, 2> : launch_encode<true, 1>)
+                         : (nw == 3 ? launch_encode<false, 3> : nw == 2 ? launch_encode<false, 2> : launch_encode<false, 1>);
+        int r = fn(grid, nw == 3 ? L3.total : nw == 2 ? L2.total : L.total, es, d_in + h.base, h.nbytes, sl.res, d_in_off, h.base,
                    (uint64_t)cut[h.b], h.nchunks, ep, d_out, d_out_off, d_out_sizes, d_status,
                    sl.opt.as<lz::OptG>(), sl.lit.as<lz::prob_t>(), lit_stride);
         if (coop) ts.coop_launches++;

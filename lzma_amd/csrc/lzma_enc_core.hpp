@@ -232,6 +232,7 @@ LZ_HD uint64_t enc_load8(const uint8_t *p) {
 enum : uint32_t {
     SY_FORK = 0,   // parses started (written by wave 0); kSyDone: the chunk is finished
     SY_JOIN,       // parses the second wave has left
+    SY_JOIN2,      // ... and the third
     SY_S,          // highest position whose round is done and whose literal candidate is published
     SY_A,          // highest position whose apply phase is done; SY_LEN_END / SY_FAR_HI belong to it
     SY_M,          // highest position whose literal candidate has been merged into the next entry
@@ -275,10 +276,12 @@ inline void lz_sy_store(uint32_t *p, uint32_t v, bool, bool = true) { __atomic_s
 inline void lz_sy_pause() { sched_yield(); }
 #endif
 
-// COOP: two waves share one chunk (parse_loop); each wave has an Encoder of its own over the
-// same LDS and HBM state, with a match-list buffer and continuation records of its own.
-template <class MF, class LP, bool COOP = false>
+// NW > 1: that many waves (two or three) share one chunk (parse_loop); each wave has an Encoder
+// of its own over the same LDS and HBM state, with a match-list buffer and continuation
+// records of its own.
+template <class MF, class LP, uint32_t NW = 1>
 struct Encoder {
+    static constexpr bool COOP = NW > 1;
     typedef LZ_LDS prob_t *PP;
     typedef LZ_LDS uint32_t *U32P;
     typedef uint16_t WT;
@@ -390,9 +393,9 @@ struct Encoder {
     // Stores from wave-uniform code are issued by one lane: 64 lanes writing the same
     // address cost the memory pipeline 64 writes.
     LZ_HD bool one() const { return lane_id == 0; }
-    // two waves at consecutive positions see windows one entry apart in the same ring: their
-    // union must fit it, so a cooperative window is one entry shorter
-    static constexpr uint32_t kWinSpan = COOP ? kRecWin - 1 : kRecWin;
+    // waves at consecutive positions see windows one entry apart in the same ring: their
+    // union must fit it, so a cooperative window is shorter by one entry per extra wave
+    static constexpr uint32_t kWinSpan = kRecWin - (NW - 1);
     LZ_HD bool in_win(uint32_t i) const { return i - wlo < kWinSpan; }
     LZ_HD bool in_bwin(uint32_t i) const { return wcur - i < kBksWin; }
     LZ_HD Rec grec(uint32_t i) const {
@@ -1154,6 +1157,7 @@ struct Encoder {
             const bool mine = parse_loop(1, position, mf0, len_end, ex);
             LZ_LAP(6)
             (void)sy_wait_word(SY_JOIN, seq, false);
+            if constexpr (NW > 2) (void)sy_wait_word(SY_JOIN2, seq, false);
             LZ_LAP(15)
             if (dead) {  // the waves lost each other: end the chunk, which reports the error
                 back_res = 0xFFFFFFFFu;
@@ -1185,7 +1189,7 @@ struct Encoder {
     };
     // second wave of a cooperative workgroup: takes part in every parse loop wave 0 starts,
     // until wave 0 reports the chunk finished
-    LZ_HD void helper_run(U32P small, U32P own) {
+    LZ_HD void helper_run(U32P small, U32P own, uint32_t wave) {  // wave: 1 or 2
         bind_small(small, ep.fb, ep.pb);
         la_tgt = own, la_price = own + la_max(ep.fb), mdist = own + la_words(ep.fb);
         pos_state_mask = (1u << ep.pb) - 1;
@@ -1200,12 +1204,14 @@ struct Encoder {
             LZ_LAP(15)
             if (dead || f == kSyDone) return;
             seq = f;
-            const uint32_t p_v = sync[SY_POS0], m_v = sync[SY_MF0], e_v = sync[SY_LEN_END], f_v = sync[SY_FAR_HI];
-            far_hi = U(f_v);
+            // (the end of the parse range and the far mark are read with every apply phase's
+            // hand-over, never before: by now the first wave may have moved them on)
+            const uint32_t p_v = sync[SY_POS0], m_v = sync[SY_MF0];
+            far_hi = 0;
             LoopExit ex;
-            (void)parse_loop(2, U(p_v), U(m_v), U(e_v), ex);
+            (void)parse_loop(1 + wave, U(p_v), U(m_v), 0, ex);
             if (dead) return;
-            sy_signal(SY_JOIN, seq);
+            sy_signal(wave == 1 ? SY_JOIN : SY_JOIN2, seq);
         }
     }
     LZ_HD void publish_exit(const LoopExit &ex) {
@@ -1246,22 +1252,30 @@ struct Encoder {
     // The main loop of a parse (:507-795), positions first_cur, first_cur + step, ...: every
     // position for a wave of its own, every other one in a cooperative workgroup.
     //
-    // Two waves (COOP).  What position c does falls into a first half S(c) -- match list, state
-    // and reps of the path into c, state prices, the round, the literal / short-rep candidate for
-    // entry c + 1 -- and a second half A(c), the apply phase over entries c + 2 and beyond.
-    // S(c) needs entry c final: the apply phases up to A(c - 2), which the same wave ran, and the
-    // literal candidate of c - 1, which the other wave publishes at the end of S(c - 1) and this
-    // wave merges into entry c itself (that candidate comes after those of A(c - 2) in the
-    // reference's order, and A(c - 1), still running, does not touch entry c).  A(c) needs
-    // A(c - 1), which changes the same entries.  So S(c + 1) runs beside A(c), and a position
-    // costs about half of what it costs one wave.  The end of the parse range (cur == lenEnd) is
-    // known when A(c - 1) is done: a wave runs S(c) before it knows whether c is parsed at all
-    // (entry c is final and valid in either case), checks, and only then lets the other wave go
-    // on to c + 1.  Returns true in the wave that found the end (ex is set), false in the other.
+    // Several waves (NW = 2 or 3), wave w taking positions w + 1, w + 1 + NW, ...  What position
+    // c does falls into three parts:
+    //   S(c)  entry c made final, state and reps of the path into c, state prices, and the
+    //         literal / short-rep candidate for entry c + 1, priced by eight lanes and published;
+    //   R(c)  the match list and the round (rep lengths, continuations);
+    //   A(c)  the apply phase over entries c + 2 and beyond.
+    // S(c) needs the candidate that S(c - 1) published -- this wave merges it into entry c
+    // itself, after the apply phases up to A(c - 2) (it comes after their candidates in the
+    // reference's order; A(c - 1), still running, does not touch entry c) -- so the S parts form
+    // a chain from wave to wave, and so do the A parts (A(c) changes the entries A(c - 1)
+    // changes); R(c) and A(c) of one position run beside S, R and A of the next ones on the other
+    // waves.  A(c) also waits for the merge of its own candidate (done by the wave at c + 1),
+    // which says whether the literal won (nextIsChar, :601-604 and :635).
+    //   The end of the parse range (cur == lenEnd, :509) is known only when A(c - 1) is done, after
+    // S(c) and R(c) have run: a wave works on a position before it is known to be parsed at all,
+    // and the wave at c + 1 may even start from an entry nothing was written to in this parse
+    // (if the parse ends at c).  Such work changes nothing that is read again -- entries beyond
+    // the end are never looked at, the window and the models are left alone -- and the few places
+    // where a stale entry could lead out of bounds are guarded (round_task, the path entry, the
+    // state).  Returns true in the wave that found the end (ex is set), false in the others.
     LZ_HD bool parse_loop(uint32_t first_cur, const uint32_t pos0, const uint32_t mf0, uint32_t len_end,
                           LoopExit &ex) {
         const uint32_t fb = ep.fb;
-        constexpr uint32_t kStep = COOP ? 2 : 1;
+        constexpr uint32_t kStep = NW;
         LZ_LANEVAR(x0);
         LZ_LANEVAR(x1);
         LZ_LANEVAR(x2);
@@ -1306,8 +1320,20 @@ struct Encoder {
             }
             uint32_t new_len = 0;
             Rec rc_, nxr;
+            // three waves have time to spare between their positions: the match list is read
+            // before the wave waits; with two, after the merge the other wave waits for
+            constexpr bool kListFirst = NW > 2;
+            if constexpr (kListFirst) {
+                if (!beyond) new_len = read_match_distances();
+                LZ_LAP(0)
+            }
             if constexpr (COOP) {
                 if (!sy_wait(SY_S, cur - 1)) return false;
+                // entry cur is final with the apply phases up to cur - 2: this wave's own with two
+                // waves, another wave's with three
+                if constexpr (NW > 2) {
+                    if (cur >= 3 && !sy_wait(SY_A, cur - 2)) return false;
+                }
                 LZ_LAP(12)
                 const Rec rc_v = o_rec[cur & (kRecWin - 1)];
                 rc_ = urec(rc_v);
@@ -1324,8 +1350,10 @@ struct Encoder {
                 }
                 LZ_LAP(8)
             }
-            if (!beyond) new_len = read_match_distances();
-            LZ_LAP(0)
+            if constexpr (!kListFirst) {
+                if (!beyond) new_len = read_match_distances();
+                LZ_LAP(0)
+            }
             uint32_t dpairs = beyond ? 0 : dist_pairs;
             if constexpr (COOP) {
                 if (beyond || new_len >= fb) {

@@ -86,7 +86,7 @@ struct ChainMFRef {
 };
 }  // namespace
 
-template <bool COOP>
+template <uint32_t NW>
 static int hs_encode_impl(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
                           uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
                           size_t *out_n) {
@@ -106,8 +106,9 @@ static int hs_encode_impl(const uint8_t *in, size_t n, uint32_t dict_log, uint32
     std::vector<lz::Reps> opt_bks(lz::kBksWin);
     std::vector<uint32_t> small(lz::enc_small_words(fb, pb));
     lz::build_prob_prices(pp.data(), 0, 1);
-    std::vector<uint32_t> sync(lz::SY_WORDS, 0), own1(lz::la_words(fb) + lz::mdist_words(fb));
-    lz::Encoder<ChainMFRef, lz::prob_t *, COOP> e;
+    const size_t own_words = lz::la_words(fb) + lz::mdist_words(fb);
+    std::vector<uint32_t> sync(lz::SY_WORDS, 0), own(2 * own_words);
+    lz::Encoder<ChainMFRef, lz::prob_t *, NW> e;
     e.sync = sync.data();
     e.data = padded.data();
     e.n = (uint32_t)n;
@@ -125,12 +126,15 @@ static int hs_encode_impl(const uint8_t *in, size_t n, uint32_t dict_log, uint32
     e.ep = ep;
     e.lane_id = 0;
     lz::write_header(out, ep, eos ? -1 : (int64_t)n);
-    if (COOP) {
-        // the second wave of a cooperative workgroup is a second thread over the same memory
-        lz::Encoder<ChainMFRef, lz::prob_t *, COOP> h = e;
-        std::thread t([&] { h.helper_run(small.data(), own1.data()); });
+    if (NW > 1) {
+        // the other waves of a cooperative workgroup are threads over the same memory
+        lz::Encoder<ChainMFRef, lz::prob_t *, NW> h1 = e, h2 = e;
+        std::thread t1([&] { h1.helper_run(small.data(), own.data(), 1); });
+        std::thread t2;
+        if (NW > 2) t2 = std::thread([&] { h2.helper_run(small.data(), own.data() + own_words, 2); });
         e.run(small.data());
-        t.join();
+        t1.join();
+        if (NW > 2) t2.join();
     } else {
         e.run(small.data());
     }
@@ -141,11 +145,16 @@ static int hs_encode_impl(const uint8_t *in, size_t n, uint32_t dict_log, uint32
 extern "C" int hs_encode(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
                          uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
                          size_t *out_n) {
-    return hs_encode_impl<false>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
+    return hs_encode_impl<1>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
 }
-// the same through the cooperative parse loop, one thread per wave
+// the same through the cooperative parse loop, one thread per wave (two waves, three waves)
 extern "C" int hs_encode_coop(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
                               uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
                               size_t *out_n) {
-    return hs_encode_impl<true>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
+    return hs_encode_impl<2>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
+}
+extern "C" int hs_encode_coop3(const uint8_t *in, size_t n, uint32_t dict_log, uint32_t fb, uint32_t lc,
+                               uint32_t lp, uint32_t pb, int eos, uint8_t *out, size_t out_cap,
+                               size_t *out_n) {
+    return hs_encode_impl<3>(in, n, dict_log, fb, lc, lp, pb, eos, out, out_cap, out_n);
 }

@@ -72,7 +72,7 @@ def hostsim():
     L.hs_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.hs_encode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p, C.c_size_t,
                                                                          C.POINTER(C.c_size_t)]
-    L.hs_encode_coop.argtypes = L.hs_encode.argtypes
+    L.hs_encode_coop.argtypes = L.hs_encode_coop3.argtypes = L.hs_encode.argtypes
     return L
 
 
@@ -83,11 +83,11 @@ def _hs_decode(L, stream, cap=1 << 20):
     return rc, out[: n.value].tobytes()
 
 
-def _hs_encode(L, raw, dict_log, fb, lc=3, lp=0, pb=2, eos=True, coop=False):
+def _hs_encode(L, raw, dict_log, fb, lc=3, lp=0, pb=2, eos=True, waves=1):
     cap = len(raw) * 2 + 1024
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
-    fn = L.hs_encode_coop if coop else L.hs_encode
+    fn = {1: L.hs_encode, 2: L.hs_encode_coop, 3: L.hs_encode_coop3}[waves]
     rc = fn(raw, len(raw), dict_log, fb, lc, lp, pb, int(eos), out.ctypes.data, cap, C.byref(n))
     assert rc == 0
     return out[: n.value].tobytes()
@@ -110,13 +110,13 @@ def test_kernel_decode_core_on_host(hostsim, vectors, data_txt, data_lzma):
 def test_kernel_encode_core_on_host(hostsim, data_txt, cfg):
     """The encoder kernel's core, compiled for the host with a brute-force exhaustive
     finder, equals the oracle with the cut value raised, byte for byte: as one wave, and as
-    the cooperative pair of waves (two host threads over the same memory)."""
+    two and three cooperating waves (host threads over the same memory)."""
     from oracle import oracle as O
     dl, fb, lc, lp, pb, eos = cfg
     for raw in (b"", b"a", b"hello world\n", data_txt[:80000]):
         want = O.encode(raw, O.params(dict_log=dl, fb=fb, lc=lc, lp=lp, pb=pb, cut=1 << 30, eos=eos))
-        assert _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos) == want
-        assert _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos, coop=True) == want
+        for waves in (1, 2, 3):
+            assert _hs_encode(hostsim, raw, dl, fb, lc, lp, pb, eos, waves=waves) == want, waves
 
 
 def test_exhaustive_cut_stays_within_one_percent(data_txt):

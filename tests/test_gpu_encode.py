@@ -19,11 +19,11 @@ pytestmark = pytest.mark.gpu
 CUT_INF = 1 << 30
 
 
-@pytest.fixture(autouse=True, params=["one wave per chunk", "two waves per chunk"])
+@pytest.fixture(autouse=True, params=["one wave per chunk", "two waves per chunk", "three waves per chunk"])
 def waves_per_chunk(request, monkeypatch):
-    """Every test of this file runs under both encoder kernels: the library reads LZMA_AMD_COOP at
-    each call (0: one wave per chunk, 1: the cooperative kernel with two; unset: by chunk count)."""
-    monkeypatch.setenv("LZMA_AMD_COOP", "0" if request.param.startswith("one") else "1")
+    """Every test of this file runs under all three encoder kernels: the library reads LZMA_AMD_COOP
+    at each call (0: one wave per chunk, 2 / 3: the cooperative kernels; unset: by chunk count)."""
+    monkeypatch.setenv("LZMA_AMD_COOP", {"one": "0", "two": "2", "three": "3"}[request.param.split()[0]])
 
 
 def _check(chunks, *, dict_log, fb, lc=3, lp=0, pb=2, eos=False, ratio_check=True):
