@@ -588,6 +588,34 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, 3>, 192, L3.total);
         if (e == hipSuccess && api > 0) resident3 = (unsigned)api * S.shape.cus;
     }
+    // Several waves per chunk when the call has so few chunks that wave slots would stay empty:
+    // three if every chunk can have a resident workgroup of three, else two if half of the
+    // slots would be empty otherwise.  (Not for the last launches of a larger call: they run
+    // beside earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
+    // in sum than one does -- measured on 4096 chunks: 18.8 s against 15.8 s.)
+    unsigned nw_call = 1;
+    if (coop_ok && coop_mode != 0) {
+        if (coop_mode == 2 || coop_mode == 3)
+            nw_call = (unsigned)coop_mode;
+        else if (coop_mode == 1)
+            nw_call = 2;
+        else if (n_chunks <= resident3)
+            nw_call = 3;
+        else if (2 * (uint64_t)n_chunks <= resident)
+            nw_call = 2;
+    }
+    // the stream each launch goes to: one whose previous launch is done if there is one (a
+    // launch queued behind a running one waits a whole chunk time), else in turn
+    int stream_slot[kEncStreams];
+    for (int &v : stream_slot) v = -1;
+    auto pick_stream = [&](size_t b) -> int {
+        for (int i = 0; i < (int)in_flight; i++) {
+            const int k = (int)((b + i) % in_flight);
+            if (stream_slot[k] < 0 || !slots[stream_slot[k]].busy || hipEventQuery(slots[stream_slot[k]].e1) == hipSuccess)
+                return k;
+        }
+        return (int)(b % in_flight);
+    };
     auto running = [&]() -> int {
         int n = 0;
         for (int i = 0; i < nslots; i++)
@@ -596,25 +624,12 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
     };
     auto launch = [&](const Held &h) -> int {
         Slot &sl = slots[h.b % nslots];
-        hipStream_t es = S.enc[h.b % in_flight];
+        const int sk = pick_stream(h.b);
+        stream_slot[sk] = (int)(h.b % nslots);
+        hipStream_t es = S.enc[sk];
         const unsigned grid = std::min(h.nchunks, grid_cap);
         LZ_HIP_BAIL(hipEventRecord(sl.e0, es));
-        // Several waves per chunk when the call has so few chunks that wave slots would stay empty:
-        // three if every chunk can have a resident workgroup of three, else two if half of the
-        // slots would be empty otherwise.  (Not for the last launches of a larger call: they run
-        // beside earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
-        // in sum than one does -- measured on 4096 chunks: 18.8 s against 15.8 s.)
-        unsigned nw = 1;
-        if (coop_ok && coop_mode != 0) {
-            if (coop_mode == 2 || coop_mode == 3)
-                nw = (unsigned)coop_mode;
-            else if (coop_mode == 1)
-                nw = 2;
-            else if (n_chunks <= resident3)
-                nw = 3;
-            else if (2 * (uint64_t)n_chunks <= resident)
-                nw = 2;
-        }
+        const unsigned nw = nw_call;
         const bool coop = nw > 1;
         auto fn = packed ? (nw == 3 ? launch_encode<true, 3> : nw == 2 ? launch_encode<true, 2> : launch_encode<true, 1>)
                          : (nw == 3 ? launch_encode<false, 3> : nw == 2 ? launch_encode<false, 2> : launch_encode<false, 1>);
@@ -663,7 +678,9 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
         for (const Held &h : held) slots_full |= h.b % nslots == (b + 1) % nslots;
         const bool last_generation = n_chunks - cut[held.front().b] <= resident;
         size_t n_launch = 0;
-        if (finder_done || slots_full || !last_generation)
+        // (a call that leaves most of the device empty does not slow the finder down much: its
+        // launches go out as their lists are ready)
+        if (finder_done || slots_full || !last_generation || nw_call > 1)
             n_launch = held.size();
         else {
             const int r = running();
