@@ -900,16 +900,10 @@ struct Encoder {
                     }
             if (plain && m_price < price)
                 price = m_price, back = m_dist + kNumReps, ppw = cur, is_la = false, changed = true;
-            if (changed) {
-                if (price == kInfPrice) {
-                    set_price(x, price);
-                } else if (is_la) {
-                    Rec r;
-                    r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
-                    srec(x, r);
-                } else {
-                    set_pbp(x, price, back, ppw);
-                }
+            if (changed) {  // (backPrev2 only counts with the flags of a continuation set)
+                Rec r;
+                r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
+                srec(x, r);
             }
         }
         LZ_PAR_END
@@ -980,16 +974,10 @@ struct Encoder {
                 }
                 if (plain && m_price < price)
                     price = m_price, back = m_dist + kNumReps, ppw = cur, is_la = false, changed = true;
-                if (changed) {
-                    if (price == kInfPrice) {
-                        set_price(x, price);
-                    } else if (is_la) {
-                        Rec r;
-                        r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
-                        srec(x, r);
-                    } else {
-                        set_pbp(x, price, back, ppw);
-                    }
+                if (changed) {  // (backPrev2 only counts with the flags of a continuation set)
+                    Rec r;
+                    r.price = price, r.back = back, r.pp = ppw, r.back2 = back2;
+                    srec(x, r);
                 }
             }
             LZ_PAR_END
@@ -1647,7 +1635,10 @@ struct Encoder {
 
             // ---- continuation of the literal (:635-658)
             for (uint32_t i = 0; i < 5; i++) A.lt[i] = 0, A.lp[i] = 0;
-            uint32_t new_end = len_end;
+            // new_end: first the furthest entry this position has a candidate for (the apply phase
+            // goes no further: the entries between there and the end of the parse range, reached
+            // from earlier positions, have nothing to gain here), then the new end of the range
+            uint32_t new_end = 0;
             if (!next_is_char && match_byte != cur_byte) {
                 const uint32_t l2 = lit_l2;
                 if (l2 >= 2) {
@@ -1702,6 +1693,7 @@ struct Encoder {
                 }
             }
             A.cur = cur, A.old_end = len_end, A.new_end = new_end, A.ps = ps, A.start_len = start_len;
+            if (len_end > new_end) new_end = len_end;
             A.new_len = plain_len, A.nmp = nmp, A.npairs = npairs, A.first_la = first_la;
             LZ_LAP(3)
             if (npairs <= kLanes - 8)

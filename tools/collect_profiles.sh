@@ -27,8 +27,9 @@ for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
          "l2:TCC_HIT_sum TCC_MISS_sum"; do
     n=${g%%:*}
     c=${g#*:}
-    timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -o p -- \
-        python3 "$R/bench.py" --chunks 832 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-extra > "$OUT/pmc_$n.log" 2>&1
+    # (one wave per chunk, as in the full benchmark: 832 chunks alone would get two)
+    LZMA_AMD_COOP=0 timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$n" -o p -- \
+        python3 "$R/bench.py" --chunks 832 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-extra --no-e2e > "$OUT/pmc_$n.log" 2>&1
     cp "$(find "$OUT/pmc_$n" -name '*counter_collection.csv' | head -1)" "$OUT/pmc/$n.csv"
     rm -rf "$OUT/pmc_$n"
     echo "pmc pass $n done"
