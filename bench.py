@@ -57,7 +57,7 @@ def native():
 
 def pmc_summary(name):
     """A committed rocprofv3 PMC summary (profiles/), newest round first; None if absent."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = ROOT / "profiles" / f"{rnd}_{name}.json"
         try:
             return json.loads(path.read_text())
@@ -511,14 +511,21 @@ class DecodeWorkload:
         np.cumsum(es, out=coff[1:])
         self.comp = int(coff[-1])
         d_c = torch.empty(max(self.comp, 1), dtype=torch.uint8, device=dev)
-        if self.comp:
-            idx_src = torch.repeat_interleave(d_enc_off[:-1], enc_sizes) + (
-                torch.arange(self.comp, device=dev) -
-                torch.repeat_interleave(torch.from_numpy(coff[:-1]).to(dev), enc_sizes))
-            d_c[: self.comp] = d_enc[idx_src]
+        d_coff = torch.from_numpy(coff).to(dev)
+        # in blocks of streams: index tensors of a whole 1M-stream batch would have billions of elements
+        blk = 50000
+        for a in range(0, self.ns, blk):
+            b = min(self.ns, a + blk)
+            n_b = int(coff[b] - coff[a])
+            if not n_b:
+                continue
+            sz = enc_sizes[a:b]
+            idx_src = torch.repeat_interleave(d_enc_off[a:b], sz) + (
+                torch.arange(n_b, device=dev) - torch.repeat_interleave(d_coff[a:b] - d_coff[a], sz))
+            d_c[int(coff[a]): int(coff[b])] = d_enc[idx_src]
             del idx_src
         del d_enc
-        self.d_in, self.in_off = d_c, torch.from_numpy(coff).to(dev)
+        self.d_in, self.in_off = d_c, d_coff
         self.out_off = d_raw_off
         self.d_out = torch.empty(max(self.n, 1), dtype=torch.uint8, device=dev)
         self.sizes = torch.zeros(self.ns, dtype=torch.int64, device=dev)
