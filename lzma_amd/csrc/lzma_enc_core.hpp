@@ -469,14 +469,27 @@ struct Encoder {
     LZ_HD uint32_t up1(uint32_t p) const { return U(price1(p)); }
     // Window bookkeeping when cur advances to c (by one): the entry that enters the
     // window is fetched from HBM if anything was ever written that far out.
-    LZ_HD void win_advance(uint32_t c) {
+    // The fetch is issued here (into `pend`, a local of the caller) and lands in the window when
+    // win_land() is called, after the position's match list has been read: that much work hides
+    // most of the memory round trip, and the four registers are live only across it (the
+    // kernel has none to spare further on).  Returns the window slot waiting for it, or kNoSlot.
+    static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+    LZ_HD uint32_t win_advance(uint32_t c, Rec &pend) {
         wcur = c;
+        uint32_t slot = kNoSlot;
         const uint32_t lo = c > kRecBack ? c - kRecBack : 0;
         if (lo != wlo) {
             wlo = lo;
             const uint32_t e = lo + kWinSpan - 1;
-            if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
+            if (e <= far_hi && e < kNumOpts) {
+                if (one()) pend = opt_g[e].rec;
+                slot = e & (kRecWin - 1);
+            }
         }
+        return slot;
+    }
+    LZ_HD void win_land(uint32_t slot, const Rec &pend) {
+        if (slot != kNoSlot && one()) o_rec[slot] = pend;
     }
     // COOP: the window of position c is set when the wave turns to c (win_set) and the entry it
     // gains is fetched when the apply phases of all earlier positions are done (win_enter)
@@ -1273,12 +1286,15 @@ struct Encoder {
         uint32_t cur = first_cur - kStep;
         for (;;) {
             cur += kStep;
+            Rec pend;
+            pend.price = pend.back = pend.pp = pend.back2 = 0;
+            uint32_t pend_slot = kNoSlot;
             if constexpr (!COOP) {
                 if (cur == len_end) {
                     ex.cur = cur, ex.long_match = 0, ex.longest_len = 0, ex.last_dist = 0;
                     return true;
                 }
-                win_advance(cur);
+                pend_slot = win_advance(cur, pend);
             } else {
                 win_set(cur);
                 mfpos = mf0 + cur - 1;
@@ -1340,6 +1356,7 @@ struct Encoder {
             }
             if constexpr (!kListFirst) {
                 if (!beyond) new_len = read_match_distances();
+                if constexpr (!COOP) win_land(pend_slot, pend);
                 LZ_LAP(0)
             }
             uint32_t dpairs = beyond ? 0 : dist_pairs;
