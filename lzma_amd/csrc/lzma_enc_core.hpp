@@ -50,7 +50,10 @@ constexpr uint32_t kLanes = 64;
 #define LZ_REC_WIN 64
 #endif
 constexpr uint32_t kRecWin = LZ_REC_WIN;           // power of two
-constexpr uint32_t kRecBack = (kRecWin * 3) / 8;   // entries kept behind cur
+#ifndef LZ_REC_BACK
+#define LZ_REC_BACK ((LZ_REC_WIN * 3) / 8)
+#endif
+constexpr uint32_t kRecBack = LZ_REC_BACK;         // entries kept behind cur
 constexpr uint32_t kBksWin = kRecWin / 2;          // power of two
 // Sizes that follow from the number of fast bytes: a match list holds at most fb - 1
 // pairs (lengths 2..fb, strictly increasing), and lengths above fb are never priced.
@@ -598,25 +601,87 @@ struct Encoder {
             }
         }
     }
+    // Up to eight bits whose models are all known before the first is coded (the nodes of one
+    // walk down a bit tree): lane i fetches and updates the model of bit i (ix: its index, bt: the
+    // bit), one memory round trip for the walk instead of one per bit; the range coder then takes
+    // the models from the lanes.  The indices of one call are distinct.
     template <class P>
-    LZ_HD void bt_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {
-        uint32_t k = 1;
-        for (uint32_t i = nbits; i != 0;) {
-            i--;
-            uint32_t b = (sym >> i) & 1;
-            rc_bit(pr, base + k, b);
-            k = (k << 1) | b;
+    LZ_HD void rc_encode_lanes(P pr, LZ_LANEARG(ix), LZ_LANEARG(bt), uint32_t nbits) {
+        LZ_LANEVAR(pv);
+        LZ_LANES_BEGIN(L)
+        if (L < nbits) {
+            const uint32_t p = pr[LZ_LV(ix, L)];
+            LZ_LV(pv, L) = p;
+            pr[LZ_LV(ix, L)] = (prob_t)(LZ_LV(bt, L) ? p - (p >> kMoveBits) : p + ((kProbTotal - p) >> kMoveBits));
+        }
+        LZ_LANES_END
+        for (uint32_t i = 0; i < nbits; i++) {  // range_coder.go:205-220
+            const uint32_t p = LZ_FROM_LANE(pv, i), bit = LZ_FROM_LANE(bt, i);
+            const uint32_t bound = (range >> kProbBits) * p;
+            if (bit == 0) {
+                range = bound;
+            } else {
+                low += bound;
+                range -= bound;
+            }
+            if (range < kTopValue) {
+                range <<= 8;
+                rc_shift_low();
+            }
         }
     }
+#ifndef LZ_BATCH_BT
+#define LZ_BATCH_BT 0
+#endif
+#ifndef LZ_BATCH_LIT
+#define LZ_BATCH_LIT 1
+#endif
+    static constexpr bool kBatchBt = COOP || LZ_BATCH_BT, kBatchLit = COOP || LZ_BATCH_LIT;
     template <class P>
-    LZ_HD void bt_rev_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {
-        uint32_t k = 1;
-        for (uint32_t i = 0; i < nbits; i++) {
-            uint32_t b = sym & 1;
-            rc_bit(pr, base + k, b);
-            k = (k << 1) | b;
-            sym >>= 1;
+    LZ_HD void bt_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {  // nbits <= 8
+        if constexpr (!kBatchBt) {
+            uint32_t k = 1;
+            for (uint32_t i = nbits; i != 0;) {
+                i--;
+                uint32_t b = (sym >> i) & 1;
+                rc_bit(pr, base + k, b);
+                k = (k << 1) | b;
+            }
+            return;
         }
+        LZ_LANEVAR(ix);
+        LZ_LANEVAR(bt);
+        LZ_LANES_BEGIN(L)
+        if (L < nbits) {  // depth L: the node is 1 followed by the L highest bits of the symbol
+            LZ_LV(ix, L) = base + ((1u << L) | (sym >> (nbits - L)));
+            LZ_LV(bt, L) = (sym >> (nbits - 1 - L)) & 1;
+        }
+        LZ_LANES_END
+        rc_encode_lanes(pr, ix, bt, nbits);
+    }
+    template <class P>
+    LZ_HD void bt_rev_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {  // nbits <= 8
+        if constexpr (!kBatchBt) {
+            uint32_t k = 1;
+            for (uint32_t i = 0; i < nbits; i++) {
+                uint32_t b = sym & 1;
+                rc_bit(pr, base + k, b);
+                k = (k << 1) | b;
+                sym >>= 1;
+            }
+            return;
+        }
+        LZ_LANEVAR(ix);
+        LZ_LANEVAR(bt);
+        LZ_LANES_BEGIN(L)
+        if (L < nbits) {  // depth L: 1 followed by the L lowest bits of the symbol, lowest first
+            uint32_t k = 1;
+            for (uint32_t t = 0; t < L; t++) k = (k << 1) | ((sym >> t) & 1);
+            LZ_LV(ix, L) = base + k;
+            LZ_LV(bt, L) = (sym >> L) & 1;
+        }
+        LZ_LANES_END
+        rc_encode_lanes(pr, ix, bt, nbits);
     }
 
     // ----------------------------------------------------------------- prices
@@ -703,26 +768,52 @@ struct Encoder {
         return (((pos & lit_pos_mask) << ep.lc) + (prev >> (8 - ep.lc))) * 0x300u;
     }
     LZ_HD void lit_encode(uint32_t sub, uint32_t sym) {  // :47-55
-        uint32_t ctx = 1;
-        for (int i = 7; i >= 0; i--) {
-            uint32_t b = (sym >> i) & 1;
-            rc_bit(lit, sub + ctx, b);
-            ctx = (ctx << 1) | b;
+        if constexpr (!kBatchLit) {
+            uint32_t ctx = 1;
+            for (int i = 7; i >= 0; i--) {
+                uint32_t b = (sym >> i) & 1;
+                rc_bit(lit, sub + ctx, b);
+                ctx = (ctx << 1) | b;
+            }
+            return;
         }
+        LZ_LANEVAR(ix);
+        LZ_LANEVAR(bt);
+        LZ_LANES_BEGIN(L)
+        if (L < 8) {
+            LZ_LV(ix, L) = sub + ((0x100u | sym) >> (8 - L));
+            LZ_LV(bt, L) = (sym >> (7 - L)) & 1;
+        }
+        LZ_LANES_END
+        rc_encode_lanes(lit, ix, bt, 8);
     }
     LZ_HD void lit_encode_matched(uint32_t sub, uint32_t mb, uint32_t sym) {  // :57-76
-        uint32_t ctx = 1;
-        bool same = true;
-        for (int i = 7; i >= 0; i--) {
-            uint32_t b = (sym >> i) & 1, st = ctx;
-            if (same) {
-                uint32_t m = (mb >> i) & 1;
-                st += (1 + m) << 8;
-                same = (m == b);
+        if constexpr (!kBatchLit) {
+            uint32_t ctx = 1;
+            bool same = true;
+            for (int i = 7; i >= 0; i--) {
+                uint32_t b = (sym >> i) & 1, st = ctx;
+                if (same) {
+                    uint32_t m = (mb >> i) & 1;
+                    st += (1 + m) << 8;
+                    same = (m == b);
+                }
+                rc_bit(lit, sub + st, b);
+                ctx = (ctx << 1) | b;
             }
-            rc_bit(lit, sub + st, b);
-            ctx = (ctx << 1) | b;
+            return;
         }
+        LZ_LANEVAR(ix);
+        LZ_LANEVAR(bt);
+        LZ_LANES_BEGIN(L)
+        if (L < 8) {  // in the matched tables while all higher bits equal the match byte's
+            const bool same = ((sym ^ mb) >> (8 - L)) == 0;
+            const uint32_t m = (mb >> (7 - L)) & 1;
+            LZ_LV(ix, L) = sub + ((0x100u | sym) >> (8 - L)) + (same ? (1 + m) << 8 : 0u);
+            LZ_LV(bt, L) = (sym >> (7 - L)) & 1;
+        }
+        LZ_LANES_END
+        rc_encode_lanes(lit, ix, bt, 8);
     }
     // getPrice, :78-102, without the data-dependent loop exit: bit i is priced in the
     // matched tables while all higher bits of the symbol equal those of the match byte.
