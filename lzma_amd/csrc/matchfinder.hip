@@ -808,6 +808,7 @@ struct FinderWs {
     int device = -1;
     lzh::MfScratch scratch;
     lzh::MfResult res;
+    lzh::DevBuf joff, offs, temp;  // job offsets, pair offsets (if the caller keeps none), scan scratch
 };
 // never destroyed on its own: at process exit the HIP runtime may already be gone
 thread_local FinderWs *g_fws = nullptr;
@@ -818,6 +819,7 @@ void lzh::release_finder_workspace() {
     (void)hipDeviceSynchronize();
     g_fws->scratch.release();
     g_fws->res.release();
+    g_fws->joff.release(), g_fws->offs.release(), g_fws->temp.release();
     g_fws->device = -1;
 }
 
@@ -856,9 +858,11 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     ws.alone = true;
     int rc = ws.build(d_data, N, dict_size, fb, st);
     if (rc) return rc;
-    lzh::DevBuf joff;
+    // (everything this call needs beyond the caller's buffers is kept with the tables: no
+    // allocation, and so no wait for the device, once a thread has seen its largest stream)
+    lzh::DevBuf &joff = g_fws->joff;
     const uint64_t h_joff[2] = {0, n};
-    LZ_HIP(joff.alloc(16));
+    if (!joff.p) LZ_HIP(joff.alloc(16));
     LZ_HIP(hipMemcpyAsync(joff.p, h_joff, 16, hipMemcpyHostToDevice, st));
     uint64_t total = 0;
     t_scan.start(st);
@@ -868,22 +872,23 @@ extern "C" int lzma_amd_bt4_matches_dev(const uint8_t *d_data, size_t n, uint32_
     const unsigned g = grid_for(N, 256);
     hipLaunchKernelGGL(mf_counts_kernel, dim3(g), dim3(256), 0, st, res.d_meta(), N, d_counts);
     LZ_HIP(hipMemcpyAsync(d_total_pairs, &total, 8, hipMemcpyHostToDevice, st));
-    lzh::DevBuf offs;
     if ((d_pairs && total <= pairs_cap) || d_offsets) {
-        LZ_HIP(offs.alloc(n * 8));
+        // the offsets go straight into the caller's array if there is one
+        uint64_t *offs = d_offsets;
+        if (!offs) {
+            if (g_fws->offs.bytes < n * 8) LZ_HIP(g_fws->offs.alloc(n * 8));
+            offs = g_fws->offs.as<uint64_t>();
+        }
         size_t bytes = 0;
         auto in = rocprim::make_transform_iterator(d_counts, [] __device__(uint32_t c) { return (uint64_t)c; });
-        LZ_HIP(rocprim::exclusive_scan(nullptr, bytes, in, offs.as<uint64_t>(), (uint64_t)0, n,
-                                       rocprim::plus<uint64_t>(), st));
-        lzh::DevBuf temp;
-        LZ_HIP(temp.alloc(bytes));
-        LZ_HIP(rocprim::exclusive_scan(temp.p, bytes, in, offs.as<uint64_t>(), (uint64_t)0, n,
-                                       rocprim::plus<uint64_t>(), st));
-        LZ_HIP(hipStreamSynchronize(st));
-        if (d_offsets) LZ_HIP(hipMemcpyAsync(d_offsets, offs.p, n * 8, hipMemcpyDeviceToDevice, st));
+        LZ_HIP(rocprim::exclusive_scan(nullptr, bytes, in, offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
+        lzh::DevBuf &temp = g_fws->temp;
+        if (temp.bytes < bytes) LZ_HIP(temp.alloc(bytes));
+        bytes = temp.bytes;
+        LZ_HIP(rocprim::exclusive_scan(temp.p, bytes, in, offs, (uint64_t)0, n, rocprim::plus<uint64_t>(), st));
         if (d_pairs && total <= pairs_cap)
             hipLaunchKernelGGL(mf_gather_kernel, dim3(g), dim3(256), 0, st, res.d_meta(), res.d_arena(), N,
-                               offs.as<uint64_t>(), d_pairs, (uint64_t)pairs_cap, ws.view.packed);
+                               offs, d_pairs, (uint64_t)pairs_cap, ws.view.packed);
     }
     t_all.stop();
     LZ_HIP(hipGetLastError());
