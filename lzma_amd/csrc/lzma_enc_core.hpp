@@ -500,11 +500,18 @@ struct Encoder {
         wcur = c;
         wlo = c > kRecBack ? c - kRecBack : 0;
     }
-    LZ_HD void win_enter(uint32_t c) {
+    // (issued as soon as the earlier apply phases are done, landed with win_land() just before
+    // this position's own apply phase: the waits and scalar work in between hide the round trip)
+    LZ_HD uint32_t win_enter(uint32_t c, Rec &pend) {
+        uint32_t slot = kNoSlot;
         if (c > kRecBack) {
             const uint32_t e = c - kRecBack + kWinSpan - 1;
-            if (e <= far_hi && e < kNumOpts && one()) o_rec[e & (kRecWin - 1)] = opt_g[e].rec;
+            if (e <= far_hi && e < kNumOpts) {
+                if (one()) pend = opt_g[e].rec;
+                slot = e & (kRecWin - 1);
+            }
         }
+        return slot;
     }
     LZ_HD void note_far(uint32_t hi) {  // an apply phase wrote entries up to hi
         if (hi >= wlo + kWinSpan && hi > far_hi) far_hi = hi;
@@ -1729,12 +1736,13 @@ struct Encoder {
                     publish_exit(ex);
                     return true;
                 }
+                pend_slot = win_enter(cur, pend);
                 if (!sy_wait(SY_M, cur)) return false;
                 LZ_LAP(14)
                 const uint32_t n_v = sync[SY_NIC + (cur & 1)];
                 next_is_char = U(n_v) != 0;
-                win_enter(cur);
                 if (!do_rest) {
+                    win_land(pend_slot, pend);
                     sy_signal(SY_A, cur);  // len_end and far_hi stay as they are
                     continue;
                 }
@@ -1804,6 +1812,7 @@ struct Encoder {
             if (len_end > new_end) new_end = len_end;
             A.new_len = plain_len, A.nmp = nmp, A.npairs = npairs, A.first_la = first_la;
             LZ_LAP(3)
+            if constexpr (COOP) win_land(pend_slot, pend);
             if (npairs <= kLanes - 8)
                 apply_lanes(A, x0, x1, x2);
             else
