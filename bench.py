@@ -216,19 +216,29 @@ def dist_init(backend, rehearse=False):
     cuda = backend == "nccl"
     if cuda:
         torch.cuda.set_device(local if world > 1 else 0)
-    if world > 1:
+    # a launcher's single rank (torch.distributed.run --nproc-per-node 1) goes through the process
+    # group as well: every collective of a step then runs over RCCL with one rank, which is how a
+    # box with one GPU exercises that path
+    if world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if cuda:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if rank == 0:
+            note(f"process group: {dist.get_backend()}, {world} rank(s)")
     dev = torch.device("cuda", local if world > 1 else 0) if cuda else torch.device("cpu")
     return rank, world, dev
 
 
+def group_up():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier_sync(world, dev):
-    if world > 1:
+    if world > 1 or group_up():
         import torch.distributed as dist
         dist.barrier()
     if dev.type == "cuda":
@@ -236,7 +246,7 @@ def barrier_sync(world, dev):
 
 
 def reduce_ranks(x, world, dev, op):
-    if world == 1:
+    if world == 1 and not group_up():
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if COLL_CPU else dev)
@@ -937,7 +947,7 @@ def main():
                 "mf": extra_leg("mf", lambda: MfWorkload(0, 1, dev, args.mib), 555.0),
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if group_up():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

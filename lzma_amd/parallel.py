@@ -63,9 +63,11 @@ def gather_ragged(local_sizes: torch.Tensor, counts, rank: int, world: int, grou
     the same `counts`): one all-gather, padded to the widest share when the shares differ.
     Used with shard_by_bytes, whose shares differ in length by design."""
     local_sizes = local_sizes.to(torch.int64)
-    if world == 1:
-        return local_sizes
     import torch.distributed as dist
+    # (a single rank inside a process group still goes through the collective: that is how the
+    # exchange is exercised on a box with one device)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_sizes
     counts = [int(c) for c in counts]
     if len(counts) != world:
         raise ValueError(f"{len(counts)} counts for {world} ranks")

@@ -218,6 +218,31 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["config"]["chunks_total"] == 65 and line["config"]["chunks_this_rank"] == 33
 
 
+def test_bench_single_rank_over_rccl():
+    """bench.py under the launcher the multi-GPU runs use, with one rank: the process group is
+    created with the RCCL backend on the device, and the barrier, the size all-gather (encode: even
+    shares; decode: the padded form) and the reductions of a step run through it on device tensors."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for extra in (["--chunks", "9"], ["--workload", "decode", "--streams", "300"]):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1",
+                            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--no-e2e"] + extra,
+                           cwd=root, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0
+        assert "process group: nccl" in r.stderr, r.stderr[-2000:]
+
+
 def _bench_line(args, timeout):
     import json
     import os

@@ -1,6 +1,6 @@
 """One encode call on synthetic data, for rocprofv3 runs and timing experiments.
 
-    python tools/prof_encode.py [nchunks] [chunk_bytes] [dict_log] [fb] [markov|log] [verify]
+    python tools/prof_encode.py [nchunks] [chunk_bytes] [dict_log] [fb] [markov|log] [verify|-] [pb]
 """
 import ctypes as C
 import sys
@@ -25,11 +25,11 @@ out_off = torch.arange(0, (nchunks + 1) * cap, cap, dtype=torch.int64, device=de
 d_out = torch.empty(nchunks * cap, dtype=torch.uint8, device=dev)
 sizes = torch.zeros(nchunks, dtype=torch.int64, device=dev)
 status = torch.zeros(nchunks, dtype=torch.int32, device=dev)
-p = codec.make_params(dict_log, fb)
+p = codec.make_params(dict_log, fb, pb=int(sys.argv[7]) if len(sys.argv) > 7 else 2)
 N.check(L.lzma_amd_encode_chunks_dev(d_in.data_ptr(), in_off.data_ptr(), nchunks, n, C.byref(p), d_out.data_ptr(),
                                      out_off.data_ptr(), sizes.data_ptr(), status.data_ptr(), None))
 print("positions", n, N.last_timing(), "ratio", sizes.sum().item() / n, flush=True)
-if len(sys.argv) > 6:  # round trip of every stream through the GPU decoder
+if len(sys.argv) > 6 and sys.argv[6] == "verify":  # round trip of every stream through the GPU decoder
     off = out_off.cpu().numpy()
     sz = sizes.cpu().numpy()
     streams = [d_out[int(off[i]): int(off[i]) + int(sz[i])].cpu().numpy().tobytes() for i in range(nchunks)]
