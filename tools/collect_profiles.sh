@@ -46,7 +46,7 @@ for g in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
     n=${g%%:*}
     c=${g#*:}
     timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmcd_$n" -o p -- \
-        python3 "$R/bench.py" --workload decode --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmcd_$n.log" 2>&1
+        python3 "$R/bench.py" --workload decode --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-e2e > "$OUT/pmcd_$n.log" 2>&1
     python3 "$R/tools/pmc_sum.py" "$OUT/pmcd_$n" decode_kernel > "$OUT/pmc_dec/$n.txt"
     rm -rf "$OUT/pmcd_$n"
     echo "decode pmc pass $n done"

@@ -80,7 +80,7 @@ def decode_summaries(run, prof, tag):
     per["hbm_bytes_per_output_byte_reported"] = round((v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / out_bytes, 2)
     res = {
         "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --workload decode --steps 1 "
-                   "--warmup 0 --no-cpu-baseline --no-verify  (one run per counter group: FETCH_SIZE | WRITE_SIZE | "
+                   "--warmup 0 --no-cpu-baseline --no-verify --no-e2e  (one run per counter group: FETCH_SIZE | WRITE_SIZE | "
                    "SQ_* | TCC_HIT_sum TCC_MISS_sum)",
         "workload": f"batched decode, {same['config']['streams_total']} streams of 4-64 KiB, {out_bytes:,} output bytes, MI355X",
         "notes": ["values are per output byte, summed over all waves of decode_kernel<false>",
