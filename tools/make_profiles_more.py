@@ -41,3 +41,36 @@ if (run / "bench_decode_1M.txt").exists():
            "bench_line": json.loads(bench_line(run / "bench_decode_1M.txt"))}
     (prof / f"{tag}_bench_decode_1M_streams.json").write_text(json.dumps(res, indent=1) + "\n")
 print("ok")
+
+
+def c5(run5):
+    """... and what tools/collect_c5.sh left (a directory given as the fourth argument)."""
+    import csv
+    import re
+    rows = []
+    for r in csv.DictReader(open(run5 / "c5_kernel_stats_raw.csv")):
+        m = re.search(r"(encode_kernel<[^>]*>|(mf|rs)_\w+_kernel|radix_sort_onesweep\w*|scan_impl|__amd_rocclr_\w+)", r["Name"])
+        rows.append({"kernel": m.group(1) if m else r["Name"][:60], "calls": int(r["Calls"]),
+                     "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 1), "avg_ms": round(float(r["AverageNs"]) / 1e6, 2)})
+    pmc = {}
+    for name, f in (("encode", "c5_pmc_sq_encode.txt"), ("scan", "c5_pmc_sq_scan.txt")):
+        t = (run5 / f).read_text()
+        if "{" in t:
+            pmc[name] = ast.literal_eval(t[t.index("{"):t.index("}") + 1])
+    res = {
+        "command": "python bench.py --workload c5 --chunks 256 --steps 1 --warmup 0 --no-extra --no-e2e   (kernel stats: the same "
+                   "under rocprofv3 --kernel-trace --stats with --no-cpu-baseline --no-verify; counters: one SQ pass on --chunks 64)",
+        "workload": "configs[4]: 256 chunks of 16 MiB redundant dpkg-style log = 4 GiB, dict 64 MiB, fb 273, one MI355X",
+        "bench_line": json.loads(bench_line(run5 / "bench_c5.txt")),
+        "kernel_stats": rows[:16],
+        "pmc_sq_64_chunks": pmc,
+        "notes": ["SQ cycle counters in units of four cycles, summed over all waves of the kernel",
+                  "a chunk is one dependent chain: three waves work on it (encode_kernel<.., 3u>), batches are launched as their "
+                  "match lists are ready"],
+    }
+    (prof / f"{tag}_c5_256x16MiB.json").write_text(json.dumps(res, indent=1) + "\n")
+
+
+if len(sys.argv) > 4:
+    c5(Path(sys.argv[4]))
+    print("c5 ok")
