@@ -643,13 +643,7 @@ struct Encoder {
 #ifndef LZ_BATCH_LIT
 #define LZ_BATCH_LIT 1
 #endif
-#ifndef LZ_COOP_BATCH_BT
-#define LZ_COOP_BATCH_BT 1
-#endif
-#ifndef LZ_COOP_BATCH_LIT
-#define LZ_COOP_BATCH_LIT 1
-#endif
-    static constexpr bool kBatchBt = (COOP && LZ_COOP_BATCH_BT) || LZ_BATCH_BT, kBatchLit = (COOP && LZ_COOP_BATCH_LIT) || LZ_BATCH_LIT;
+    static constexpr bool kBatchBt = COOP || LZ_BATCH_BT, kBatchLit = COOP || LZ_BATCH_LIT;
     template <class P>
     LZ_HD void bt_encode(P pr, uint32_t base, uint32_t nbits, uint32_t sym) {  // nbits <= 8
         if constexpr (!kBatchBt) {
@@ -1414,10 +1408,7 @@ struct Encoder {
             LZ_LANEVAR(cb8);
             LZ_LANEVAR(sub8);
             LZ_LANEVAR(np8);
-#ifndef LZ_COOP_EARLY_LIT
-#define LZ_COOP_EARLY_LIT 1
-#endif
-            if constexpr (COOP && LZ_COOP_EARLY_LIT) {
+            if constexpr (COOP) {
                 if (!beyond) {
                     LZ_LANES_BEGIN(L)
                     if (L < 8) {
@@ -1587,12 +1578,6 @@ struct Encoder {
                 const bool mode = !st_is_char(st);
                 LZ_LANES_BEGIN(L)
                 if (L < 8) {
-                    if constexpr (!LZ_COOP_EARLY_LIT) {
-                        const uint8_t *a = data + a_off;
-                        const uint32_t cb_ = a[0], sub_ = lit_sub(position, a[-1]);
-                        LZ_LV(cb8, L) = cb_, LZ_LV(sub8, L) = sub_;
-                        LZ_LV(np8, L) = lit[sub_ + ((0x100u | cb_) >> (8 - L))];
-                    }
                     const uint32_t cb = LZ_LV(cb8, L);
                     const uint32_t mb = r0 < a_off ? data[a_off - r0 - 1] : 0;
                     const uint32_t i = 7 - L;
