@@ -5,7 +5,11 @@ the GPU decoder.  Decoder draws: truncated and corrupted copies must give the or
 output.  Prints one line per draw (a run is never silent for long); exits non-zero at the first
 difference with the draw's parameters.
 
-    python tools/soak_gpu.py [--minutes 5] [--seed 1]
+    python tools/soak_gpu.py [--minutes 5] [--seed 1] [--finder]
+
+--finder: draws for the match finder alone instead (data kind, length, dictionary down to far
+below the length, fast bytes): counts and pairs of every position equal to the oracle's tree
+search with its cut value raised.
 """
 import argparse
 import os
@@ -58,6 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--finder", action="store_true")
     a = ap.parse_args()
     O.lib()
     r = np.random.default_rng(a.seed)
@@ -65,6 +70,23 @@ def main():
     log = synth.logtext(4 << 20, block=1 << 20)
     t_end = time.time() + a.minutes * 60
     it = 0
+    while a.finder and time.time() < t_end:
+        it += 1
+        n = int(r.integers(1, 150000)) if it % 9 else int(r.integers(0, 40))
+        kind, data = draw_data(r, max(n, 1), markov, log)
+        data = bytes(np.asarray(data[:n], dtype=np.uint8))
+        dict_size = int(1 << int(r.integers(12, 24))) if it % 3 else int(r.integers(4096, 1 << 18))
+        fb = int(r.choice([5, 6, 8, 16, 32, 33, 64, 128, 255, 256, 272, 273]))
+        what = dict(it=it, n=n, kind=kind, dict_size=dict_size, fb=fb, seed=a.seed)
+        c_ref, p_ref = O.bt4_matches(data, dict_size, fb, cut=1 << 30)
+        c_gpu, p_gpu = lzma_amd.bt4_matches(data, dict_size, fb)
+        if not (np.array_equal(c_ref[:n], c_gpu[:n]) and np.array_equal(p_ref, p_gpu)):
+            print("MATCH LISTS DIFFER", what, int(c_ref[:n].sum()), int(c_gpu[:n].sum()), flush=True)
+            return 1
+        print(f"ok {it} n={n} kind={kind} dict={dict_size} fb={fb} -> {len(p_ref)} pairs", flush=True)
+    if a.finder:
+        print(f"finder soak done: {it} draws, no difference", flush=True)
+        return 0
     while time.time() < t_end:
         it += 1
         n = int(r.integers(1, 120000)) if it % 9 else int(r.integers(0, 40))
