@@ -576,7 +576,10 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
         uint32_t nbytes, nchunks;
     };
     std::vector<Held> held;
-    int co_run = 1;
+    // (a call whose chunks all fit the device at once ends one chain time after the finder's last
+    // batch whatever is launched earlier, so nothing runs beside its finder: 2048 chunks of 1 MiB
+    // 9.2 -> 8.5 s, 3072 chunks unchanged)
+    int co_run = n_chunks <= resident ? 0 : 1;
     if (const char *e = getenv("LZMA_AMD_CO_RUN")) co_run = std::max(0, atoi(e));
     int coop_mode = -1;  // -1: by the number of chunks, 0: one wave per chunk, 1 or 2: two waves, 3: three
     if (const char *e = getenv("LZMA_AMD_COOP")) coop_mode = atoi(e);
