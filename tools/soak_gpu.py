@@ -5,7 +5,7 @@ the GPU decoder.  Decoder draws: truncated and corrupted copies must give the or
 output.  Prints one line per draw (a run is never silent for long); exits non-zero at the first
 difference with the draw's parameters.
 
-    python tools/soak_gpu.py [--minutes 5] [--seed 1] [--finder]
+    python tools/soak_gpu.py [--minutes 5] [--seed 1] [--finder] [--max-bytes 120000]
 
 --finder: draws for the match finder alone instead (data kind, length, dictionary down to far
 below the length, fast bytes): counts and pairs of every position equal to the oracle's tree
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--finder", action="store_true")
+    ap.add_argument("--max-bytes", type=int, default=120000, help="largest input drawn (up to 3 MiB)")
     a = ap.parse_args()
     O.lib()
     r = np.random.default_rng(a.seed)
@@ -72,7 +73,7 @@ def main():
     it = 0
     while a.finder and time.time() < t_end:
         it += 1
-        n = int(r.integers(1, 150000)) if it % 9 else int(r.integers(0, 40))
+        n = int(r.integers(1, a.max_bytes)) if it % 9 else int(r.integers(0, 40))
         kind, data = draw_data(r, max(n, 1), markov, log)
         data = bytes(np.asarray(data[:n], dtype=np.uint8))
         dict_size = int(1 << int(r.integers(12, 24))) if it % 3 else int(r.integers(4096, 1 << 18))
@@ -89,7 +90,7 @@ def main():
         return 0
     while time.time() < t_end:
         it += 1
-        n = int(r.integers(1, 120000)) if it % 9 else int(r.integers(0, 40))
+        n = int(r.integers(1, a.max_bytes)) if it % 9 else int(r.integers(0, 40))
         kind, data = draw_data(r, max(n, 1), markov, log)
         data = bytes(np.asarray(data[:n], dtype=np.uint8))
         dict_log = int(r.integers(12, 27))
