@@ -139,3 +139,18 @@ def test_synth_is_deterministic():
     assert s.min() >= 4096 and s.max() <= 65536 and 15000 < s.mean() < 30000
     lg = synth.logtext(1 << 16, block=1 << 16)
     assert lg[:5].tobytes() == b"2010-"
+
+
+def test_encoder_core_under_sanitizers():
+    """The host build of the encoder core with AddressSanitizer and UndefinedBehaviorSanitizer: 24
+    drawn inputs and parameter sets, one / two / three waves per chunk (the cooperative ones on
+    real threads), identical streams and no report."""
+    import subprocess
+    d = ROOT / "tests" / "hostsim"
+    subprocess.run(["make", "-s", "sanitize_check"], cwd=d, check=True, capture_output=True, timeout=600)
+    import os
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0")  # (a preloaded library may come first)
+    r = subprocess.run([str(d / "sanitize_check"), str(ROOT / "tests" / "golden" / "data.txt")], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" same") == 24 and "DIFFERENT" not in r.stdout and "runtime error" not in r.stderr
