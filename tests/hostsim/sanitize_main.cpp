@@ -1,7 +1,7 @@
 // Drives the host build of the encoder core (hostsim.cpp: one, two and three "waves" per chunk, the
 // cooperative ones as real threads) over a few dozen drawn inputs and parameter sets; built with
 // AddressSanitizer and UndefinedBehaviorSanitizer by `make sanitize_check`.  The three widths must
-// agree byte for byte, and the sanitizers must stay silent.
+// agree byte for byte, the decoder core must invert them, and the sanitizers must stay silent.
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
@@ -9,6 +9,7 @@
 #include <random>
 extern "C" int hs_encode(const uint8_t *, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint8_t *, size_t, size_t *);
 extern "C" int hs_encode_coop3(const uint8_t *, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint8_t *, size_t, size_t *);
+extern "C" int hs_decode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_n);
 extern "C" int hs_encode_coop(const uint8_t *, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint8_t *, size_t, size_t *);
 int main(int argc, char **argv) {
     FILE *f = fopen(argv[1], "rb");
@@ -30,6 +31,14 @@ int main(int argc, char **argv) {
         hs_encode_coop(in.data(), n, dict_log, fb, lc, lp, pb, eos, b.data(), b.size(), &nb);
         hs_encode_coop3(in.data(), n, dict_log, fb, lc, lp, pb, eos, c.data(), c.size(), &nc);
         bool same = na == nb && na == nc && !memcmp(a.data(), b.data(), na) && !memcmp(a.data(), c.data(), na);
+        // ... and the decoder core takes the stream back to the input, and a cut copy to a prefix of it
+        std::vector<uint8_t> back(n + 512);
+        size_t nd = 0;
+        const int rc = hs_decode(a.data(), na, back.data(), n + 273, &nd);
+        same = same && rc == 0 && nd == n && !memcmp(back.data(), in.data(), n);
+        std::vector<uint8_t> cut(a.begin(), a.begin() + na / 2);
+        (void)hs_decode(cut.data(), cut.size(), back.data(), n + 273, &nd);
+        same = same && nd <= n && !memcmp(back.data(), in.data(), nd);
         if (!same) bad++;
         printf("%d n=%zu kind=%d dict=%u fb=%u -> %zu %s\n", it, n, kind, dict_log, fb, na, same ? "same" : "DIFFERENT");
     }
