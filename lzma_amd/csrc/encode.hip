@@ -583,17 +583,23 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
     if (const char *e = getenv("LZMA_AMD_CO_RUN")) co_run = std::max(0, atoi(e));
     int coop_mode = -1;  // -1: by the number of chunks, 0: one wave per chunk, 1 or 2: two waves, 3: three
     if (const char *e = getenv("LZMA_AMD_COOP")) coop_mode = atoi(e);
-    // workgroups of three waves the device holds at once
-    unsigned resident3 = 0;
+    // workgroups of three and of two waves the device holds at once (the cooperative kernels need
+    // more registers than the one-wave kernel: two of their waves fit a SIMD, not three)
+    unsigned resident3 = 0, resident2 = 0;
     if (coop_ok) {
         int api = 0;
         hipError_t e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, 3>, 192, L3.total)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, 3>, 192, L3.total);
         if (e == hipSuccess && api > 0) resident3 = (unsigned)api * S.shape.cus;
+        api = 0;
+        e = packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<true, 2>, 128, L2.total)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, encode_kernel<false, 2>, 128, L2.total);
+        if (e == hipSuccess && api > 0) resident2 = (unsigned)api * S.shape.cus;
     }
     // Several waves per chunk when the call has so few chunks that wave slots would stay empty:
-    // three if every chunk can have a resident workgroup of three, else two if half of the
-    // slots would be empty otherwise.  (Not for the last launches of a larger call: they run
+    // three if every chunk can have a resident workgroup of three, else two if every chunk can
+    // have one of two (1280 and 1536 chunks of 1 MiB, which do not: 7.9 and 8.6 s with two waves,
+    // the workgroups beyond the resident ones waiting a chain's time, against 7.8 and 8.3 s with one).  (Not for the last launches of a larger call: they run
     // beside earlier ones, every slot is taken, and two waves hold a chunk's slots for longer
     // in sum than one does -- measured on 4096 chunks: 18.8 s against 15.8 s.)
     unsigned nw_call = 1;
@@ -604,7 +610,7 @@ int encode_impl(const uint8_t *d_in, const uint64_t *d_in_off, size_t n_chunks, 
             nw_call = 2;
         else if (n_chunks <= resident3)
             nw_call = 3;
-        else if (2 * (uint64_t)n_chunks <= resident)
+        else if (n_chunks <= resident2)
             nw_call = 2;
     }
     // the stream each launch goes to: one whose previous launch is done if there is one (a
